@@ -1,0 +1,219 @@
+/*
+ * kifs_hip.h -- C ABI of the MI355X-native raymarching library (libkifs_hip.so).
+ *
+ * Drop-in boundary for the one hot path of LesbianLemon/kifs-raymarching: the
+ * per-pixel sphere-tracing fragment shader.  The reference has no FFI today;
+ * the seam this ABI replaces is `GraphicState` (src/render/graphics.rs:25-37):
+ *
+ *   reference call (file:line)                         this ABI
+ *   -------------------------------------------------  ---------------------------
+ *   GraphicState::new            graphics.rs:183-232   kifs_create
+ *   update_screen_data           graphics.rs:262-266   kifs_set_screen   (12 B image)
+ *   zoom_camera / rotate_camera  graphics.rs:268-302   kifs_set_camera   (64 B image)
+ *   update_options               graphics.rs:304-308   kifs_set_options  (80 B image)
+ *   render (set_pipeline by fractal_group, bind group,
+ *           draw(0..3, 0..2))    graphics.rs:310-325   kifs_render / kifs_render_async
+ *   drop(RenderState)            application.rs:86-91  kifs_destroy
+ *
+ * The three uniform structs are byte-identical to the reference's Pod structs
+ * (src/data.rs:17-49) and to the WGSL declarations
+ * (src/shaders/dependencies/bindings.wgsl:1-35), so a Rust host passes
+ * `bytemuck::bytes_of(&data.into_buffer_data())` unchanged.
+ *
+ * Plain pointers and sizes only; no exceptions cross the boundary; every entry
+ * point returns a KifsStatus.  A context is not thread-safe: one caller thread
+ * per context, mirroring the reference's single winit thread
+ * (src/application.rs:37-48).
+ */
+#ifndef KIFS_HIP_H
+#define KIFS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KIFS_ABI_VERSION 1
+
+/* ---- uniform images (data.rs:17-49) --------------------------------------- */
+
+typedef struct KifsScreenUniform { /* ScreenUniformData, data.rs:17-23 */
+    float width;
+    float height;
+    float aspect_ratio;
+} KifsScreenUniform; /* 12 bytes */
+
+typedef struct KifsCameraUniform { /* CameraUniformData, data.rs:25-31 */
+    float origin[3];
+    uint32_t _padding;
+    float matrix[3][4]; /* mat3x3 as 3 columns with 16-byte stride (packed.rs:78-92) */
+} KifsCameraUniform; /* 64 bytes */
+
+typedef struct KifsOptionsUniform { /* OptionsUniformData, data.rs:33-49 */
+    int32_t max_iterations;
+    float max_distance;
+    float epsilon;
+    uint32_t _padding1;
+    float fractal_color[3]; /* linear RGB */
+    uint32_t _padding2;
+    float background_color[3];
+    uint32_t is_heatmap;
+    uint32_t fractal_group_id; /* KifsFractalGroup, scene.rs:4-11 */
+    uint32_t primitive_id;     /* KifsPrimitiveShape, scene.rs:35-45 */
+    float power;
+    uint32_t _padding3;
+    float constant[4]; /* quaternion (real, i, j, k) */
+} KifsOptionsUniform; /* 80 bytes */
+
+typedef enum KifsFractalGroup { /* data/scene.rs:4-11 */
+    KIFS_GROUP_KIFS = 0,
+    KIFS_GROUP_JULIA = 1,
+    KIFS_GROUP_GEN_JULIA = 2
+} KifsFractalGroup;
+
+typedef enum KifsPrimitiveShape { /* data/scene.rs:35-45 */
+    KIFS_PRIM_SPHERE = 0,
+    KIFS_PRIM_CYLINDER = 1,
+    KIFS_PRIM_BOX = 2,
+    KIFS_PRIM_TORUS = 3,
+    KIFS_PRIM_SIERPINSKI = 4,
+    KIFS_PRIM_BUNNY = 5
+} KifsPrimitiveShape;
+
+/* Colour-target encoding: the reference picks the first sRGB surface format if
+ * any, else formats[0] (render.rs:72-80); blend REPLACE (graphics.rs:87-91). */
+typedef enum KifsEncode {
+    KIFS_ENCODE_UNORM = 0, /* linear -> UNORM8 */
+    KIFS_ENCODE_SRGB = 1   /* linear -> sRGB OETF -> UNORM8 (alpha stays linear) */
+} KifsEncode;
+
+/* Status codes; taxonomy follows src/error.rs:66-92. */
+typedef enum KifsStatus {
+    KIFS_OK = 0,
+    KIFS_ERR_NO_DEVICE = 1,    /* ~ RenderStateError::RequestAdapter */
+    KIFS_ERR_DEVICE_INIT = 2,  /* ~ RenderStateError::RequestDevice */
+    KIFS_ERR_BAD_SIZE = 3,     /* ~ RenderError::SurfaceMissized; zero size (render.rs:211) */
+    KIFS_ERR_UNCONFIGURED = 4, /* render before all three uniforms were set */
+    KIFS_ERR_RUNTIME = 5,      /* HIP error: fatal for the context */
+    KIFS_ERR_COMM = 6,         /* RCCL error */
+    KIFS_ERR_BAD_ARG = 7       /* null pointer, unknown enum value, bad range */
+} KifsStatus;
+
+typedef struct kifs_ctx kifs_ctx;
+
+/* ---- lifetime --------------------------------------------------------------
+ * Replaces GraphicState::new (graphics.rs:183-232) + adapter/device request
+ * (render.rs:42-69).  Binds the context to HIP device `device_ordinal`, creates
+ * its stream and events and uploads the sRGB threshold table.  Returns NULL
+ * and sets *status on failure. */
+kifs_ctx* kifs_create(int device_ordinal, int* status);
+
+/* Replaces the explicit drop (application.rs:86-91).  NULL is a no-op. */
+void kifs_destroy(kifs_ctx* ctx);
+
+/* ---- uniforms (each call COPIES its argument, like queue.write_buffer) ------ */
+int kifs_set_screen(kifs_ctx* ctx, const KifsScreenUniform* screen);    /* graphics.rs:262 */
+int kifs_set_camera(kifs_ctx* ctx, const KifsCameraUniform* camera);    /* graphics.rs:268,280 */
+int kifs_set_options(kifs_ctx* ctx, const KifsOptionsUniform* options); /* graphics.rs:304 */
+
+/* The reference hard-codes JULIA_ITERATIONS = 100, JULIA_NORMAL_ITERATIONS = 10
+ * (julia.wgsl:2-3, gen_julia.wgsl:2-3) and 10 Sierpinski folds (kifs.wgsl:72).
+ * Those are the defaults; BASELINE configs override them.  All must be >= 0. */
+int kifs_set_iters(kifs_ctx* ctx, int sdf_iters, int normal_iters, int fold_iters);
+
+/* ---- render ---------------------------------------------------------------
+ * Replaces GraphicState::render (graphics.rs:310-325): pipeline chosen by
+ * options.fractal_group_id, one kernel launch instead of draw(0..3, 0..2).
+ *
+ * Renders rows [y0, y1) of the W x H frame (W, H from the screen uniform; pixel
+ * coordinates stay global, so a band is bit-identical to the same rows of the
+ * full frame).  Row y goes to out + (y - y0) * pitch_bytes, 4 bytes per pixel,
+ * R G B A.  pitch_bytes >= 4*W and a multiple of 4.
+ *
+ * kifs_render: `out` may be a device pointer of the context's device or a host
+ * pointer; returns once `out` holds the pixels.
+ * kifs_render_async: `out` must be device memory; the launch is enqueued on
+ * `hip_stream` (a hipStream_t; NULL = the context's own stream) and the call
+ * returns without synchronising. */
+int kifs_render(kifs_ctx* ctx, uint8_t* out_rgba8, size_t pitch_bytes, int y0, int y1,
+                int encode);
+int kifs_render_async(kifs_ctx* ctx, void* hip_stream, uint8_t* dev_out_rgba8,
+                      size_t pitch_bytes, int y0, int y1, int encode);
+
+/* Contiguous row-band partition used for multi-GPU frames: rank r
+ * of `world` owns rows [y0, y1); bands differ by at most one row. */
+int kifs_band_range(int height, int rank, int world, int* y0, int* y1);
+
+/* Device time of the most recent kifs_render on this context in ms (HIP events
+ * on the launch stream), or a negative value if none completed. */
+double kifs_last_kernel_ms(kifs_ctx* ctx);
+
+/* Blocks until everything the context enqueued on its own stream is done. */
+int kifs_synchronize(kifs_ctx* ctx);
+
+const char* kifs_strerror(int status);
+int kifs_abi_version(void);
+
+/* ---- point evaluation (parity tests and tooling) -----------------------------
+ * Evaluates scene_SDF and get_normal of the current options at `n` points
+ * (xyz triples, host pointers) on the device.  Either output may be NULL. */
+int kifs_eval_points(kifs_ctx* ctx, const float* points_xyz, int n, float* sdf_out,
+                     float* normal_out_xyz);
+
+/* Evaluates one of the library's f32 elementary functions on the device over
+ * `n` host values.  fn: 0 log, 1 log2, 2 exp2, 3 sin, 4 cos, 5 acos,
+ * 6 pow(x, y) with y = `param`, 7 sRGB-encode (result as float code),
+ * 8 UNORM-encode. */
+int kifs_eval_math(kifs_ctx* ctx, int fn, const float* in, float param, float* out, int n);
+
+/* ---- host model: the reference's scene -> uniform packing --------------------
+ * C++ restatement of the caller side of the boundary so a harness without the
+ * Rust host produces the same 156 bytes.
+ *   kifs_host_screen   ScreenData::into_buffer_data        data.rs:66-81
+ *   kifs_host_camera   CameraData::into_buffer_data        data.rs:91-129
+ *   kifs_host_options  OptionsData::from(GuiData) + pack   data.rs:176-220, packed.rs:116-139
+ *   kifs_host_rotate   GraphicState::rotate_camera         graphics.rs:280-302
+ *   kifs_host_zoom     GraphicState::zoom_camera           graphics.rs:268-278
+ */
+typedef struct KifsGuiData { /* GuiData, data.rs:131-143 */
+    uint32_t max_iterations;
+    float max_distance;
+    float epsilon;
+    uint8_t fractal_color[3];    /* sRGB bytes */
+    uint8_t background_color[3]; /* sRGB bytes */
+    uint8_t is_heatmap;
+    uint8_t _reserved;
+    uint32_t fractal_group;
+    uint32_t primitive_shape;
+    float power;
+    float constant[4];
+} KifsGuiData;
+
+typedef struct KifsCameraData { /* CameraData, data.rs:83-88 */
+    float origin_distance;
+    float min_distance;
+    float phi;   /* angles.0 */
+    float theta; /* angles.1 */
+} KifsCameraData;
+
+void kifs_host_gui_default(KifsGuiData* out);       /* GuiData::default, data.rs:145-160 */
+void kifs_host_camera_default(KifsCameraData* out); /* CameraData::default, data.rs:105-113 */
+int kifs_host_screen(uint32_t width, uint32_t height, KifsScreenUniform* out);
+int kifs_host_camera(const KifsCameraData* camera, KifsCameraUniform* out);
+int kifs_host_options(const KifsGuiData* gui, KifsOptionsUniform* out);
+int kifs_host_rotate(KifsCameraData* camera, float delta_phi, float delta_theta);
+int kifs_host_zoom(KifsCameraData* camera, float distance);
+/* Mouse semantics of render.rs:255-270 / :239-250: degrees = -dx/10, +dy/10. */
+int kifs_host_mouse_motion(KifsCameraData* camera, double dx, double dy);
+float kifs_host_radians_from_degrees(float degrees); /* math.rs:429-431 */
+void kifs_host_camera_matrix(const KifsCameraData* camera, float m_colmajor[9]);
+void kifs_host_rotation_matrix(int axis, float radians, float m_colmajor[9]); /* math.rs:386-416 */
+void kifs_host_mat3_mul(const float a[9], const float b[9], float out[9]);    /* math.rs:326-353 */
+void kifs_host_mat3_vec(const float a[9], const float v[3], float out[3]);    /* math.rs:355-367 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KIFS_HIP_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libkifs_hip.so (include/kifs_hip.h).
+
+There is no fallback: if the shared library is missing or does not load, importing
+this module raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C kifs_raymarching_amd/csrc`.
+"""
+import ctypes as C
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libkifs_hip.so"
+
+KIFS_OK = 0
+STATUS_NAMES = {0: "OK", 1: "NO_DEVICE", 2: "DEVICE_INIT", 3: "BAD_SIZE", 4: "UNCONFIGURED",
+                5: "RUNTIME", 6: "COMM", 7: "BAD_ARG"}
+
+ENCODE_UNORM, ENCODE_SRGB = 0, 1
+
+
+class ScreenUniform(C.Structure):  # data.rs:17-23
+    _fields_ = [("width", C.c_float), ("height", C.c_float), ("aspect_ratio", C.c_float)]
+
+
+class CameraUniform(C.Structure):  # data.rs:25-31
+    _fields_ = [("origin", C.c_float * 3), ("_padding", C.c_uint32),
+                ("matrix", (C.c_float * 4) * 3)]
+
+
+class OptionsUniform(C.Structure):  # data.rs:33-49
+    _fields_ = [("max_iterations", C.c_int32), ("max_distance", C.c_float),
+                ("epsilon", C.c_float), ("_padding1", C.c_uint32),
+                ("fractal_color", C.c_float * 3), ("_padding2", C.c_uint32),
+                ("background_color", C.c_float * 3), ("is_heatmap", C.c_uint32),
+                ("fractal_group_id", C.c_uint32), ("primitive_id", C.c_uint32),
+                ("power", C.c_float), ("_padding3", C.c_uint32),
+                ("constant", C.c_float * 4)]
+
+
+class GuiDataC(C.Structure):  # KifsGuiData
+    _fields_ = [("max_iterations", C.c_uint32), ("max_distance", C.c_float),
+                ("epsilon", C.c_float), ("fractal_color", C.c_uint8 * 3),
+                ("background_color", C.c_uint8 * 3), ("is_heatmap", C.c_uint8),
+                ("_reserved", C.c_uint8), ("fractal_group", C.c_uint32),
+                ("primitive_shape", C.c_uint32), ("power", C.c_float),
+                ("constant", C.c_float * 4)]
+
+
+class CameraDataC(C.Structure):  # KifsCameraData
+    _fields_ = [("origin_distance", C.c_float), ("min_distance", C.c_float),
+                ("phi", C.c_float), ("theta", C.c_float)]
+
+
+assert C.sizeof(ScreenUniform) == 12
+assert C.sizeof(CameraUniform) == 64
+assert C.sizeof(OptionsUniform) == 80
+
+# every symbol include/kifs_hip.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+_ctx = C.c_void_p
+_f32p = _P(C.c_float)
+SIGNATURES = {
+    "kifs_create": (_ctx, [C.c_int, _P(C.c_int)]),
+    "kifs_destroy": (None, [_ctx]),
+    "kifs_set_screen": (C.c_int, [_ctx, _P(ScreenUniform)]),
+    "kifs_set_camera": (C.c_int, [_ctx, _P(CameraUniform)]),
+    "kifs_set_options": (C.c_int, [_ctx, _P(OptionsUniform)]),
+    "kifs_set_iters": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
+    "kifs_render": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "kifs_render_async": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                    C.c_int]),
+    "kifs_band_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "kifs_last_kernel_ms": (C.c_double, [_ctx]),
+    "kifs_synchronize": (C.c_int, [_ctx]),
+    "kifs_strerror": (C.c_char_p, [C.c_int]),
+    "kifs_abi_version": (C.c_int, []),
+    "kifs_eval_points": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, _f32p]),
+    "kifs_eval_math": (C.c_int, [_ctx, C.c_int, _f32p, C.c_float, _f32p, C.c_int]),
+    "kifs_host_gui_default": (None, [_P(GuiDataC)]),
+    "kifs_host_camera_default": (None, [_P(CameraDataC)]),
+    "kifs_host_screen": (C.c_int, [C.c_uint32, C.c_uint32, _P(ScreenUniform)]),
+    "kifs_host_camera": (C.c_int, [_P(CameraDataC), _P(CameraUniform)]),
+    "kifs_host_options": (C.c_int, [_P(GuiDataC), _P(OptionsUniform)]),
+    "kifs_host_rotate": (C.c_int, [_P(CameraDataC), C.c_float, C.c_float]),
+    "kifs_host_zoom": (C.c_int, [_P(CameraDataC), C.c_float]),
+    "kifs_host_mouse_motion": (C.c_int, [_P(CameraDataC), C.c_double, C.c_double]),
+    "kifs_host_radians_from_degrees": (C.c_float, [C.c_float]),
+    "kifs_host_camera_matrix": (None, [_P(CameraDataC), _f32p]),
+    "kifs_host_rotation_matrix": (None, [C.c_int, C.c_float, _f32p]),
+    "kifs_host_mat3_mul": (None, [_f32p, _f32p, _f32p]),
+    "kifs_host_mat3_vec": (None, [_f32p, _f32p, _f32p]),
+}
+
+
+class KifsError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        name = STATUS_NAMES.get(status, str(status))
+        super().__init__(f"kifs: {what + ': ' if what else ''}{name} ({status})")
+
+
+def _load():
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library has not been built "
+            "(run __graft_entry__.build() or make -C kifs_raymarching_amd/csrc). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kifs_abi_version() != 1:
+        raise ImportError("libkifs_hip.so: ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what=""):
+    if status != KIFS_OK:
+        raise KifsError(status, what)

@@ -1,0 +1,379 @@
+// kifs_api.cpp -- the C ABI of include/kifs_hip.h: context lifetime, uniform upload,
+// frame render.  Host code only; kernels live in kifs_kernels.hip.
+//
+// A kifs_ctx plays the part of the reference's GraphicState (render/graphics.rs:25-37):
+// it owns the "device objects" (stream, events, the sRGB table in HBM, a scratch frame
+// for host-destination renders) and a copy of the three uniform images.  There is no
+// CPU path: every entry point that produces pixels launches the HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/kifs_hip.h"
+#include "kifs_internal.hpp"
+
+static_assert(sizeof(KifsScreenUniform) == 12, "ScreenUniformData is 12 bytes (data.rs:17-23)");
+static_assert(sizeof(KifsCameraUniform) == 64, "CameraUniformData is 64 bytes (data.rs:25-31)");
+static_assert(sizeof(KifsOptionsUniform) == 80, "OptionsUniformData is 80 bytes (data.rs:33-49)");
+static_assert(offsetof(KifsCameraUniform, matrix) == 16, "camera.matrix at byte 16");
+static_assert(offsetof(KifsOptionsUniform, fractal_color) == 16, "fractal_color at byte 16");
+static_assert(offsetof(KifsOptionsUniform, background_color) == 32, "background_color at 32");
+static_assert(offsetof(KifsOptionsUniform, is_heatmap) == 44, "is_heatmap at 44");
+static_assert(offsetof(KifsOptionsUniform, power) == 56, "power at 56");
+static_assert(offsetof(KifsOptionsUniform, constant) == 64, "constant at 64");
+
+struct kifs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    float* d_srgb = nullptr;       // 256 thresholds
+    uint8_t* d_scratch = nullptr;  // frame staging for host destinations
+    size_t scratch_bytes = 0;
+    KifsScreenUniform screen{};
+    KifsCameraUniform camera{};
+    KifsOptionsUniform options{};
+    bool have_screen = false, have_camera = false, have_options = false;
+    int sdf_iters = 100, normal_iters = 10, fold_iters = 10;  // julia.wgsl:2-3, kifs.wgsl:72
+    double last_ms = -1.0;
+    bool timing_pending = false;
+};
+
+namespace {
+
+struct DeviceGuard {  // make ctx's device current for the duration of a call
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+int frame_dims(const kifs_ctx* c, int* w, int* h) {
+    // width/height arrive as f32 (data.rs:71-73 casts u32 -> f32); demand exact integers
+    float fw = c->screen.width, fh = c->screen.height;
+    if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return KIFS_ERR_BAD_SIZE;
+    if (fw != std::floor(fw) || fh != std::floor(fh)) return KIFS_ERR_BAD_SIZE;
+    *w = int(fw);
+    *h = int(fh);
+    return KIFS_OK;
+}
+
+int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
+    int w, h;
+    int st = frame_dims(c, &w, &h);
+    if (st != KIFS_OK) return st;
+    const KifsCameraUniform& cam = c->camera;
+    const KifsOptionsUniform& o = c->options;
+    if (o.fractal_group_id > 2u) return KIFS_ERR_BAD_ARG;  // FractalGroup::from_id -> None
+    P->height = c->screen.height;
+    P->aspect = c->screen.aspect_ratio;
+    P->origin = {cam.origin[0], cam.origin[1], cam.origin[2]};
+    P->m0 = {cam.matrix[0][0], cam.matrix[0][1], cam.matrix[0][2]};
+    P->m1 = {cam.matrix[1][0], cam.matrix[1][1], cam.matrix[1][2]};
+    P->m2 = {cam.matrix[2][0], cam.matrix[2][1], cam.matrix[2][2]};
+    P->max_iterations = o.max_iterations;
+    P->max_distance = o.max_distance;
+    P->epsilon = o.epsilon;
+    P->fractal_color = {o.fractal_color[0], o.fractal_color[1], o.fractal_color[2]};
+    P->background_color = {o.background_color[0], o.background_color[1], o.background_color[2]};
+    P->is_heatmap = o.is_heatmap;
+    P->power = o.power;
+    P->c = {o.constant[0], o.constant[1], o.constant[2], o.constant[3]};
+    P->sdf_iters = c->sdf_iters;
+    P->normal_iters = c->normal_iters;
+    P->fold_iters = c->fold_iters;
+    P->width = w;
+    P->y0 = 0;
+    P->y1 = h;
+    P->encode = KIFS_ENCODE_SRGB;
+    P->pitch_words = uint32_t(w);
+    P->out = nullptr;
+    P->srgb_table = c->d_srgb;
+    return KIFS_OK;
+}
+
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory reports an error; clear it
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int y0, int y1,
+            int encode) {
+    if (!c->have_screen || !c->have_camera || !c->have_options) return KIFS_ERR_UNCONFIGURED;
+    if (!dev_out) return KIFS_ERR_BAD_ARG;
+    if (encode != KIFS_ENCODE_UNORM && encode != KIFS_ENCODE_SRGB) return KIFS_ERR_BAD_ARG;
+    kifs::FrameParams P;
+    int st = fill_params(c, &P);
+    if (st != KIFS_OK) return st;
+    const int h = P.y1;
+    if (y0 < 0 || y1 > h || y0 > y1) return KIFS_ERR_BAD_ARG;
+    if (pitch < size_t(P.width) * 4 || (pitch & 3u) != 0 || (pitch >> 2) > 0xffffffffull)
+        return KIFS_ERR_BAD_SIZE;
+    if ((reinterpret_cast<uintptr_t>(dev_out) & 3u) != 0) return KIFS_ERR_BAD_ARG;
+    P.y0 = y0;
+    P.y1 = y1;
+    P.encode = encode;
+    P.pitch_words = uint32_t(pitch >> 2);
+    P.out = reinterpret_cast<uint32_t*>(dev_out);
+    hipError_t e = kifs::launch_render(P, c->options.fractal_group_id, c->options.primitive_id,
+                                       stream);
+    return e == hipSuccess ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kifs_abi_version(void) { return KIFS_ABI_VERSION; }
+
+const char* kifs_strerror(int status) {
+    switch (status) {
+    case KIFS_OK: return "ok";
+    case KIFS_ERR_NO_DEVICE: return "no such HIP device";
+    case KIFS_ERR_DEVICE_INIT: return "HIP device initialisation failed";
+    case KIFS_ERR_BAD_SIZE: return "bad frame size or pitch";
+    case KIFS_ERR_UNCONFIGURED: return "render before screen, camera and options were set";
+    case KIFS_ERR_RUNTIME: return "HIP runtime error";
+    case KIFS_ERR_COMM: return "RCCL communication error";
+    case KIFS_ERR_BAD_ARG: return "bad argument";
+    default: return "unknown status";
+    }
+}
+
+kifs_ctx* kifs_create(int device_ordinal, int* status) {
+    auto fail = [&](int st) -> kifs_ctx* {
+        if (status) *status = st;
+        return nullptr;
+    };
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(KIFS_ERR_NO_DEVICE);
+    }
+    if (device_ordinal < 0 || device_ordinal >= ndev) return fail(KIFS_ERR_NO_DEVICE);
+    DeviceGuard g(device_ordinal);
+    if (!g.ok) return fail(KIFS_ERR_DEVICE_INIT);
+    kifs_ctx* c = new (std::nothrow) kifs_ctx();
+    if (!c) return fail(KIFS_ERR_DEVICE_INIT);
+    c->device = device_ordinal;
+    float table[256];
+    kifs::build_srgb_thresholds(table);
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&c->ev_start) == hipSuccess &&
+              hipEventCreate(&c->ev_stop) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&c->d_srgb), sizeof table) == hipSuccess &&
+              hipMemcpy(c->d_srgb, table, sizeof table, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        kifs_destroy(c);
+        return fail(KIFS_ERR_DEVICE_INIT);
+    }
+    if (status) *status = KIFS_OK;
+    return c;
+}
+
+void kifs_destroy(kifs_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_srgb) (void)hipFree(c->d_srgb);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int kifs_set_screen(kifs_ctx* c, const KifsScreenUniform* s) {
+    if (!c || !s) return KIFS_ERR_BAD_ARG;
+    kifs_ctx probe;
+    probe.screen = *s;
+    int w, h;
+    int st = frame_dims(&probe, &w, &h);
+    if (st != KIFS_OK) return st;  // cf. render.rs:211: zero-sized frames are ignored
+    c->screen = *s;
+    c->have_screen = true;
+    return KIFS_OK;
+}
+
+int kifs_set_camera(kifs_ctx* c, const KifsCameraUniform* cam) {
+    if (!c || !cam) return KIFS_ERR_BAD_ARG;
+    c->camera = *cam;
+    c->have_camera = true;
+    return KIFS_OK;
+}
+
+int kifs_set_options(kifs_ctx* c, const KifsOptionsUniform* o) {
+    if (!c || !o) return KIFS_ERR_BAD_ARG;
+    if (o->fractal_group_id > 2u) return KIFS_ERR_BAD_ARG;
+    c->options = *o;
+    c->have_options = true;
+    return KIFS_OK;
+}
+
+int kifs_set_iters(kifs_ctx* c, int sdf_iters, int normal_iters, int fold_iters) {
+    if (!c || sdf_iters < 0 || normal_iters < 0 || fold_iters < 0) return KIFS_ERR_BAD_ARG;
+    c->sdf_iters = sdf_iters;
+    c->normal_iters = normal_iters;
+    c->fold_iters = fold_iters;
+    return KIFS_OK;
+}
+
+int kifs_band_range(int height, int rank, int world, int* y0, int* y1) {
+    if (height < 0 || world <= 0 || rank < 0 || rank >= world || !y0 || !y1)
+        return KIFS_ERR_BAD_ARG;
+    const long long h = height;
+    *y0 = int(h * rank / world);
+    *y1 = int(h * (rank + 1) / world);
+    return KIFS_OK;
+}
+
+int kifs_render_async(kifs_ctx* c, void* hip_stream, uint8_t* dev_out, size_t pitch, int y0,
+                      int y1, int encode) {
+    if (!c) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return enqueue(c, s, dev_out, pitch, y0, y1, encode);
+}
+
+int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int encode) {
+    if (!c || !out) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    const bool on_device = is_device_pointer(out);
+    uint8_t* target = out;
+    size_t tpitch = pitch;
+    if (!on_device) {
+        if (!c->have_screen) return KIFS_ERR_UNCONFIGURED;
+        int w, h;
+        int st = frame_dims(c, &w, &h);
+        if (st != KIFS_OK) return st;
+        if (y0 < 0 || y1 > h || y0 > y1) return KIFS_ERR_BAD_ARG;
+        if (pitch < size_t(w) * 4) return KIFS_ERR_BAD_SIZE;
+        tpitch = size_t(w) * 4;
+        size_t need = tpitch * size_t(y1 - y0);
+        if (need > c->scratch_bytes) {
+            if (c->d_scratch) (void)hipFree(c->d_scratch);
+            c->d_scratch = nullptr;
+            c->scratch_bytes = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&c->d_scratch), need) != hipSuccess)
+                return KIFS_ERR_RUNTIME;
+            c->scratch_bytes = need;
+        }
+        target = c->d_scratch;
+        if (need == 0) return KIFS_OK;
+    }
+    if (hipEventRecord(c->ev_start, c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+    int st = enqueue(c, c->stream, target, tpitch, y0, y1, encode);
+    if (st != KIFS_OK) return st;
+    if (hipEventRecord(c->ev_stop, c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+    if (!on_device) {
+        if (hipMemcpy2DAsync(out, pitch, target, tpitch, tpitch, size_t(y1 - y0),
+                             hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            return KIFS_ERR_RUNTIME;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
+    return KIFS_OK;
+}
+
+double kifs_last_kernel_ms(kifs_ctx* c) { return c ? c->last_ms : -1.0; }
+
+int kifs_synchronize(kifs_ctx* c) {
+    if (!c) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    return hipStreamSynchronize(c->stream) == hipSuccess ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+int kifs_eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float* nrm_out) {
+    if (!c || !pts || n < 0) return KIFS_ERR_BAD_ARG;
+    if (!c->have_options) return KIFS_ERR_UNCONFIGURED;
+    if (n == 0) return KIFS_OK;
+    DeviceGuard g(c->device);
+    kifs::FrameParams P;
+    kifs_ctx tmp = *c;  // options-only evaluation: give fill_params a valid 1x1 screen
+    tmp.screen = {1.0f, 1.0f, 1.0f};
+    int st = fill_params(&tmp, &P);
+    if (st != KIFS_OK) return st;
+    float *d_pts = nullptr, *d_sdf = nullptr, *d_nrm = nullptr;
+    int rc = KIFS_ERR_RUNTIME;
+    size_t nb = size_t(n) * sizeof(float);
+    do {
+        if (hipMalloc(reinterpret_cast<void**>(&d_pts), 3 * nb) != hipSuccess) break;
+        if (sdf_out && hipMalloc(reinterpret_cast<void**>(&d_sdf), nb) != hipSuccess) break;
+        if (nrm_out && hipMalloc(reinterpret_cast<void**>(&d_nrm), 3 * nb) != hipSuccess) break;
+        if (hipMemcpyAsync(d_pts, pts, 3 * nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) break;
+        if (kifs::launch_eval_points(P, c->options.fractal_group_id, c->options.primitive_id,
+                                     d_pts, n, d_sdf, d_nrm, c->stream) != hipSuccess) break;
+        if (sdf_out && hipMemcpyAsync(sdf_out, d_sdf, nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) break;
+        if (nrm_out && hipMemcpyAsync(nrm_out, d_nrm, 3 * nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) break;
+        rc = KIFS_OK;
+    } while (0);
+    if (d_pts) (void)hipFree(d_pts);
+    if (d_sdf) (void)hipFree(d_sdf);
+    if (d_nrm) (void)hipFree(d_nrm);
+    return rc;
+}
+
+int kifs_eval_math(kifs_ctx* c, int fn, const float* in, float param, float* out, int n) {
+    if (!c || !in || !out || n < 0 || fn < 0 || fn > 8) return KIFS_ERR_BAD_ARG;
+    if (n == 0) return KIFS_OK;
+    DeviceGuard g(c->device);
+    float *d_in = nullptr, *d_out = nullptr;
+    int rc = KIFS_ERR_RUNTIME;
+    size_t nb = size_t(n) * sizeof(float);
+    do {
+        if (hipMalloc(reinterpret_cast<void**>(&d_in), nb) != hipSuccess) break;
+        if (hipMalloc(reinterpret_cast<void**>(&d_out), nb) != hipSuccess) break;
+        if (hipMemcpyAsync(d_in, in, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) break;
+        if (kifs::launch_eval_math(fn, d_in, param, c->d_srgb, d_out, n, c->stream) != hipSuccess) break;
+        if (hipMemcpyAsync(out, d_out, nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) break;
+        rc = KIFS_OK;
+    } while (0);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"
+
+// ---- sRGB threshold table ---------------------------------------------------------------
+namespace kifs {
+
+static double oetf(double l) { return l <= 0.0031308 ? 12.92 * l : 1.055 * std::pow(l, 1.0 / 2.4) - 0.055; }
+static double eotf(double v) { return v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4); }
+
+// t[k] (k >= 1): the smallest binary32 x for which 255 * OETF(x) >= k - 0.5, located by
+// inverting in double precision and then walking single ulps until the predicate flips.
+void build_srgb_thresholds(float t[256]) {
+    t[0] = 0.0f;
+    for (int k = 1; k < 256; ++k) {
+        const double want = double(k) - 0.5;
+        float x = float(eotf(want / 255.0));
+        while (oetf(double(x)) * 255.0 < want) x = std::nextafterf(x, 2.0f);
+        while (true) {
+            float below = std::nextafterf(x, -1.0f);
+            if (oetf(double(below)) * 255.0 >= want) x = below; else break;
+        }
+        t[k] = x;
+    }
+}
+
+}  // namespace kifs

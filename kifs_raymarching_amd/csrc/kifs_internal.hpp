@@ -1,0 +1,21 @@
+// kifs_internal.hpp -- launcher prototypes shared by kifs_api.cpp and kifs_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kifs_params.hpp"
+
+namespace kifs {
+
+hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitive,
+                         hipStream_t stream);
+hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,
+                              const float* pts, int n, float* sdf, float* nrm,
+                              hipStream_t stream);
+hipError_t launch_eval_math(int fn, const float* in, float param, const float* srgb_table,
+                            float* out, int n, hipStream_t stream);
+
+// 256 sRGB thresholds: t[k] = smallest f32 whose ideal sRGB UNORM8 encoding is >= k.
+void build_srgb_thresholds(float t[256]);
+
+}  // namespace kifs

@@ -1,0 +1,175 @@
+// kifs_kernels.hip -- gfx950 kernels of the raymarching library and their launchers.
+//
+// render_kernel<GROUP, PRIM>: one thread per pixel, 256-thread workgroups.
+//   * A workgroup owns a 32 x 8 pixel tile; each of its 4 waves owns an 8 x 8
+//     sub-tile, so the 64 rays of a wave are spatially compact and drop out of the
+//     march loop at similar times (wave time = slowest lane).
+//   * Frame constants arrive as the kernel argument (scalar loads -> SGPRs); the
+//     256-entry sRGB threshold table is staged into LDS once per workgroup.
+//   * Encoded pixels go through an LDS tile so that the global store is linear:
+//     every wave-level store instruction writes two full 128-byte row segments.
+//   * Consecutive blockIdx.x are horizontal neighbours and the dispatcher deals
+//     workgroups round-robin over the 8 XCDs, so the expensive tiles at the centre of
+//     the image spread evenly over the XCDs; there is no inter-workgroup data.
+//
+// Replaces: vs_main + rasteriser + fs_main + ROP of the reference
+// (src/shaders/dependencies/entry.wgsl:35-59, src/render/graphics.rs:310-325,
+// src/render.rs:72-80).
+#include "kifs_internal.hpp"
+#include "kifs_scene.hpp"
+
+namespace kifs {
+
+constexpr int TILE_W = 32;
+constexpr int TILE_H = 8;
+constexpr int BLOCK = TILE_W * TILE_H;  // 256 threads = 4 waves
+
+template <int GROUP, int PRIM>
+__global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
+    __shared__ float s_srgb[256];
+    __shared__ uint32_t s_tile[TILE_H][TILE_W];
+
+    const int tid = threadIdx.x;
+    const bool srgb = (P.encode == 1);
+    if (srgb) s_srgb[tid] = P.srgb_table[tid];
+
+    // compute mapping: wave w -> 8x8 sub-tile w, lane -> (lane & 7, lane >> 3)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lx = (wave << 3) | (lane & 7);
+    const int ly = lane >> 3;
+    const int x = blockIdx.x * TILE_W + lx;
+    const int y = P.y0 + blockIdx.y * TILE_H + ly;
+    const bool valid = (x < P.width) && (y < P.y1);
+
+    V3 colour{0.0f, 0.0f, 0.0f};
+    if (__ballot(valid) != 0ull) {
+        V3 dir = ray_direction(P, x, y);
+        colour = raymarch<GROUP, PRIM>(P, dir, valid);
+    }
+
+    __syncthreads();  // s_srgb visible
+    uint32_t r, g, b;
+    if (srgb) {
+        r = srgb8(colour.x, s_srgb);
+        g = srgb8(colour.y, s_srgb);
+        b = srgb8(colour.z, s_srgb);
+    } else {
+        r = unorm8(colour.x);
+        g = unorm8(colour.y);
+        b = unorm8(colour.z);
+    }
+    s_tile[ly][lx] = r | (g << 8) | (b << 16) | 0xff000000u;  // alpha = 1.0 -> 255
+    __syncthreads();
+
+    // store mapping: thread -> (tid & 31, tid >> 5): linear rows of 128 bytes
+    const int sx = tid & (TILE_W - 1), sy = tid >> 5;
+    const int ox = blockIdx.x * TILE_W + sx;
+    const int oy = blockIdx.y * TILE_H + sy;  // row within the band
+    if (ox < P.width && (P.y0 + oy) < P.y1)
+        P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
+}
+
+// Pipeline selection: the reference keeps three render pipelines and picks one per
+// frame by fractal_group (graphics.rs:310-321); the KIFS shader then switches on
+// primitive_id per SDF call (kifs.wgsl:139-155).  Here both are template parameters.
+template <int GROUP, int PRIM>
+static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
+    const int rows = P.y1 - P.y0;
+    dim3 grid((P.width + TILE_W - 1) / TILE_W, (rows + TILE_H - 1) / TILE_H);
+    hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), grid, dim3(BLOCK), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitive,
+                         hipStream_t stream) {
+    if (P.y1 <= P.y0 || P.width <= 0) return hipSuccess;
+    switch (group) {
+    case GROUP_JULIA: return launch_variant<GROUP_JULIA, 0>(P, stream);
+    case GROUP_GENJULIA: return launch_variant<GROUP_GENJULIA, 0>(P, stream);
+    case GROUP_KIFS:
+        switch (primitive) {
+        case PRIM_SPHERE: return launch_variant<GROUP_KIFS, PRIM_SPHERE>(P, stream);
+        case PRIM_CYLINDER: return launch_variant<GROUP_KIFS, PRIM_CYLINDER>(P, stream);
+        case PRIM_BOX: return launch_variant<GROUP_KIFS, PRIM_BOX>(P, stream);
+        case PRIM_TORUS: return launch_variant<GROUP_KIFS, PRIM_TORUS>(P, stream);
+        case PRIM_SIERPINSKI: return launch_variant<GROUP_KIFS, PRIM_SIERPINSKI>(P, stream);
+        case PRIM_BUNNY: return launch_variant<GROUP_KIFS, PRIM_BUNNY>(P, stream);
+        default: return launch_variant<GROUP_KIFS, PRIM_OTHER>(P, stream);  // kifs.wgsl:154
+        }
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---- point evaluation (parity tests) --------------------------------------------------
+template <int GROUP, int PRIM>
+__global__ void eval_points_kernel(const FrameParams P, const float* __restrict__ pts, int n,
+                                   float* __restrict__ sdf, float* __restrict__ nrm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 p{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    if (sdf) sdf[i] = scene_sdf<GROUP, PRIM>(P, p);
+    if (nrm) {
+        V3 v = scene_normal<GROUP, PRIM>(P, p);
+        nrm[3 * i] = v.x; nrm[3 * i + 1] = v.y; nrm[3 * i + 2] = v.z;
+    }
+}
+
+template <int GROUP, int PRIM>
+static hipError_t launch_eval_variant(const FrameParams& P, const float* pts, int n, float* sdf,
+                                      float* nrm, hipStream_t stream) {
+    hipLaunchKernelGGL((eval_points_kernel<GROUP, PRIM>), dim3((n + 255) / 256), dim3(256), 0,
+                       stream, P, pts, n, sdf, nrm);
+    return hipGetLastError();
+}
+
+hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,
+                              const float* pts, int n, float* sdf, float* nrm,
+                              hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    switch (group) {
+    case GROUP_JULIA: return launch_eval_variant<GROUP_JULIA, 0>(P, pts, n, sdf, nrm, stream);
+    case GROUP_GENJULIA: return launch_eval_variant<GROUP_GENJULIA, 0>(P, pts, n, sdf, nrm, stream);
+    case GROUP_KIFS:
+        switch (primitive) {
+        case PRIM_SPHERE: return launch_eval_variant<GROUP_KIFS, PRIM_SPHERE>(P, pts, n, sdf, nrm, stream);
+        case PRIM_CYLINDER: return launch_eval_variant<GROUP_KIFS, PRIM_CYLINDER>(P, pts, n, sdf, nrm, stream);
+        case PRIM_BOX: return launch_eval_variant<GROUP_KIFS, PRIM_BOX>(P, pts, n, sdf, nrm, stream);
+        case PRIM_TORUS: return launch_eval_variant<GROUP_KIFS, PRIM_TORUS>(P, pts, n, sdf, nrm, stream);
+        case PRIM_SIERPINSKI: return launch_eval_variant<GROUP_KIFS, PRIM_SIERPINSKI>(P, pts, n, sdf, nrm, stream);
+        case PRIM_BUNNY: return launch_eval_variant<GROUP_KIFS, PRIM_BUNNY>(P, pts, n, sdf, nrm, stream);
+        default: return launch_eval_variant<GROUP_KIFS, PRIM_OTHER>(P, pts, n, sdf, nrm, stream);
+        }
+    default: return hipErrorInvalidValue;
+    }
+}
+
+__global__ void eval_math_kernel(int fn, const float* __restrict__ in, float param,
+                                 const float* __restrict__ srgb_table, float* __restrict__ out,
+                                 int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = in[i], r;
+    switch (fn) {
+    case 0: r = log_(x); break;
+    case 1: r = log2_(x); break;
+    case 2: r = exp2_(x); break;
+    case 3: r = sin_(x); break;
+    case 4: r = cos_(x); break;
+    case 5: r = acos_(x); break;
+    case 6: r = pow_(x, param); break;
+    case 7: r = float(srgb8(x, srgb_table)); break;
+    case 8: r = float(unorm8(x)); break;
+    default: r = x; break;
+    }
+    out[i] = r;
+}
+
+hipError_t launch_eval_math(int fn, const float* in, float param, const float* srgb_table,
+                            float* out, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(eval_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, in,
+                       param, srgb_table, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace kifs

@@ -1,0 +1,36 @@
+// kifs_params.hpp -- plain data shared by the host side of the library and the kernels.
+#pragma once
+
+#include <stdint.h>
+
+namespace kifs {
+
+struct V2 { float x, y; };
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };  // quaternion (real, i, j, k) -- quaternions.wgsl:2-3
+
+enum : int { GROUP_KIFS = 0, GROUP_JULIA = 1, GROUP_GENJULIA = 2 };  // data/scene.rs:4-11
+enum : int {                                                           // data/scene.rs:35-45
+    PRIM_SPHERE = 0, PRIM_CYLINDER, PRIM_BOX, PRIM_TORUS, PRIM_SIERPINSKI, PRIM_BUNNY, PRIM_OTHER
+};
+
+// Everything a frame needs, passed by value as the kernel argument (scalar loads ->
+// SGPRs).  Unpacked from the three uniform images of bindings.wgsl:1-35.
+struct FrameParams {
+    float height, aspect;               // ScreenUniform; the width is `width` below
+    V3 origin, m0, m1, m2;              // CameraUniform: origin + matrix columns
+    int max_iterations;                 // OptionsUniform
+    float max_distance, epsilon;
+    V3 fractal_color, background_color;
+    uint32_t is_heatmap;
+    float power;
+    V4 c;
+    int sdf_iters, normal_iters, fold_iters;  // julia.wgsl:2-3, kifs.wgsl:72 made parameters
+    int width, y0, y1;                  // frame width, row band [y0, y1)
+    int encode;                         // KifsEncode
+    uint32_t pitch_words;               // output row pitch in 32-bit words
+    uint32_t* out;                      // first row of the band
+    const float* srgb_table;            // 256 thresholds, device memory
+};
+
+}  // namespace kifs

@@ -1,0 +1,298 @@
+// kifs_scene.hpp -- device-side scene: the signed-distance functions, normals and
+// the sphere-tracing loop of the reference fragment shader, written for wave64.
+//
+// What each function computes is fixed by the reference (paths under
+// src/shaders/ of LesbianLemon/kifs-raymarching):
+//   julia_sdf / julia_normal        julia.wgsl:5-27 / :29-56
+//   genjulia_sdf / genjulia_normal  gen_julia.wgsl:5-27 / :30-55, quaternions.wgsl:57-63
+//   primitive SDFs, fold, Sierpinski, bunny, central-difference normal   kifs.wgsl:16-167
+//   ray set-up and march            dependencies/entry.wgsl:49-59 / :6-29
+// How it is computed is this library's own: the variant (fractal group x
+// primitive) is a template parameter so the uniform `switch` of kifs.wgsl:139-155
+// and the pipeline choice of graphics.rs:310-321 vanish at compile time; all
+// frame constants sit in SGPRs (kernarg); per-pixel state is registers only.
+#pragma once
+
+#include "kifs_bunny_weights.h"
+#include "kifs_device_math.hpp"
+
+namespace kifs {
+
+// ---- quaternion step q <- q^2 + c (quaternions.wgsl:42-50 + :26-28) ---------------
+KIFS_DEV V4 quat_sq_add(V4 q, V4 c) {
+    float d = dot(V3{q.y, q.z, q.w}, V3{q.y, q.z, q.w});
+    float tr = 2.0f * q.x;
+    return V4{fmaf_(q.x, q.x, -d) + c.x, fmaf_(tr, q.y, c.y), fmaf_(tr, q.z, c.z),
+              fmaf_(tr, q.w, c.w)};
+}
+
+// quaternions.wgsl:57-63
+KIFS_DEV V4 quat_pow(V4 q, float x) {
+    float norm = length(q);
+    float phi = acos_(q.x / norm);
+    V3 n = normalize(V3{q.y, q.z, q.w});
+    float pw = pow_(norm, x);
+    float a = x * phi;
+    float cs = cos_(a), sn = sin_(a);
+    return V4{pw * cs, pw * (n.x * sn), pw * (n.y * sn), pw * (n.z * sn)};
+}
+
+// ---- Julia ---------------------------------------------------------------------
+KIFS_DEV float julia_sdf(const FrameParams& P, V3 p) {
+    float norm = length(p);
+    if (norm > 2.0f + P.epsilon) return norm - 2.0f;  // bounding-sphere patch
+    V4 q{p.x, p.y, p.z, 0.1f};
+    float qs = dot(q, q);
+    float dqs = 1.0f;
+    for (int i = 0; i < P.sdf_iters; ++i) {
+        dqs = dqs * (4.0f * qs);
+        q = quat_sq_add(q, P.c);
+        qs = dot(q, q);
+        if (qs > P.max_distance) break;
+    }
+    return (0.25f * log_(qs)) * sqrt_(qs / dqs);
+}
+
+KIFS_DEV V3 julia_normal(const FrameParams& P, V3 p) {
+    V4 q{p.x, p.y, p.z, 0.1f};
+    // Jacobian columns; A(q) = [x -y -z -w; y x 0 0; z 0 x 0; w 0 0 x]^T-as-columns
+    // (julia.wgsl:40-45 uses the column-major constructor), J <- A*J column by column.
+    V4 j0{1, 0, 0, 0}, j1{0, 1, 0, 0}, j2{0, 0, 1, 0}, j3{0, 0, 0, 1};
+    auto apply = [&](V4 v) {
+        V4 r;
+        r.x = fmaf_(q.w, v.w, fmaf_(q.z, v.z, fmaf_(q.y, v.y, q.x * v.x)));
+        r.y = fmaf_(q.x, v.y, (-q.y) * v.x);
+        r.z = fmaf_(q.x, v.z, (-q.z) * v.x);
+        r.w = fmaf_(q.x, v.w, (-q.w) * v.x);
+        return r;
+    };
+    for (int i = 0; i < P.normal_iters; ++i) {
+        j0 = apply(j0); j1 = apply(j1); j2 = apply(j2); j3 = apply(j3);
+        q = quat_sq_add(q, P.c);
+        if (dot(q, q) > P.max_distance) break;
+    }
+    V3 g;
+    g.x = fmaf_(j3.x, q.w, fmaf_(j2.x, q.z, fmaf_(j1.x, q.y, j0.x * q.x)));
+    g.y = fmaf_(j3.y, q.w, fmaf_(j2.y, q.z, fmaf_(j1.y, q.y, j0.y * q.x)));
+    g.z = fmaf_(j3.z, q.w, fmaf_(j2.z, q.z, fmaf_(j1.z, q.y, j0.z * q.x)));
+    return normalize(g);
+}
+
+// ---- generalised Julia -----------------------------------------------------------
+KIFS_DEV float genjulia_sdf(const FrameParams& P, V3 p) {
+    float norm = length(p);
+    if (norm > 2.0f + P.epsilon) return norm - 2.0f;
+    V4 q{p.x, p.y, p.z, 0.1f};
+    float qs = dot(q, q);
+    float dqs = 1.0f;
+    const float pp = P.power * P.power;
+    const float pm1 = P.power - 1.0f;
+    for (int i = 0; i < P.sdf_iters; ++i) {
+        dqs = dqs * (pp * pow_(qs, pm1));
+        V4 t = quat_pow(q, P.power);
+        q = V4{t.x + P.c.x, t.y + P.c.y, t.z + P.c.z, t.w + P.c.w};
+        qs = dot(q, q);
+        if (qs > P.max_distance) break;
+    }
+    return (0.25f * log_(qs)) * sqrt_(qs / dqs);
+}
+
+KIFS_DEV V3 genjulia_normal(const FrameParams& P, V3 p) {
+    const float h = P.epsilon;
+    // six offset orbits (gen_julia.wgsl:35-40); `position +- h_axis` adds +-0 elsewhere
+    V4 o[6] = {
+        {p.x + h, p.y + 0.0f, p.z + 0.0f, 0.1f}, {p.x - h, p.y - 0.0f, p.z - 0.0f, 0.1f},
+        {p.x + 0.0f, p.y + h, p.z + 0.0f, 0.1f}, {p.x - 0.0f, p.y - h, p.z - 0.0f, 0.1f},
+        {p.x + 0.0f, p.y + 0.0f, p.z + h, 0.1f}, {p.x - 0.0f, p.y - 0.0f, p.z - h, 0.1f},
+    };
+    for (int i = 0; i < P.normal_iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            V4 t = quat_pow(o[k], P.power);
+            o[k] = V4{t.x + P.c.x, t.y + P.c.y, t.z + P.c.z, t.w + P.c.w};
+        }
+    }
+    float l[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) l[k] = log2_(length(o[k]));
+    return normalize(V3{l[0] - l[1], l[2] - l[3], l[4] - l[5]});
+}
+
+// ---- KIFS ------------------------------------------------------------------------
+// Mirror in a plane through the origin with normal e_a + e_b (kifs.wgsl:6-14 with the
+// normals of :58-62): signed distance (pa+pb)/|n|, reflect only from the negative side.
+KIFS_DEV void mirror2(float& pa, float& pb) {
+    const float len = sqrt_(2.0f);
+    const float nn = 1.0f / len;
+    float sd = (pa + pb) / len;
+    float k = 2.0f * min_(sd, 0.0f);
+    pa = fmaf_(-k, nn, pa);
+    pb = fmaf_(-k, nn, pb);
+}
+
+KIFS_DEV V3 tetrahedral_fold(V3 p) {  // kifs.wgsl:56-66
+    mirror2(p.x, p.y);
+    mirror2(p.y, p.z);
+    mirror2(p.x, p.z);
+    return p;
+}
+
+KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p) {  // kifs.wgsl:68-81
+    float scale = 1.0f;
+    float r = length(p);
+    for (int i = 0; i < P.fold_iters && r < P.max_distance; ++i) {
+        p = tetrahedral_fold(p);
+        scale = scale * 2.0f;
+        p = V3{fmaf_(2.0f, p.x, -1.0f), fmaf_(2.0f, p.y, -1.0f), fmaf_(2.0f, p.z, -1.0f)};
+        r = length(p);
+    }
+    return (r - 2.0f) / scale;
+}
+
+KIFS_DEV V4 mat4_vec(const float* m, V4 v) {  // column-major 4x4 times vector
+    V4 r;
+    r.x = fmaf_(m[12], v.w, fmaf_(m[8], v.z, fmaf_(m[4], v.y, m[0] * v.x)));
+    r.y = fmaf_(m[13], v.w, fmaf_(m[9], v.z, fmaf_(m[5], v.y, m[1] * v.x)));
+    r.z = fmaf_(m[14], v.w, fmaf_(m[10], v.z, fmaf_(m[6], v.y, m[2] * v.x)));
+    r.w = fmaf_(m[15], v.w, fmaf_(m[11], v.z, fmaf_(m[7], v.y, m[3] * v.x)));
+    return r;
+}
+KIFS_DEV V4 add4(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+KIFS_DEV V4 sin4(V4 a) { return V4{sin_(a.x), sin_(a.y), sin_(a.z), sin_(a.w)}; }
+KIFS_DEV V4 ld4(const float* v) { return V4{v[0], v[1], v[2], v[3]}; }
+
+KIFS_DEV float bunny_sdf(V3 p) {  // kifs.wgsl:84-137; weights in constant memory
+    if (dot(p, p) > 1.0f) return length(p) - 0.8f;
+    V4 q{p.x * -1.0f, p.z * 1.0f, p.y * -1.0f, 1.0f};
+    V4 f0[4], f1[4], f2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f0[k] = sin4(mat4_vec(KIFS_BUNNY_L0[k], q));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        V4 a = mat4_vec(KIFS_BUNNY_L1[k][0], f0[0]);
+        a = add4(a, mat4_vec(KIFS_BUNNY_L1[k][1], f0[1]));
+        a = add4(a, mat4_vec(KIFS_BUNNY_L1[k][2], f0[2]));
+        a = add4(a, mat4_vec(KIFS_BUNNY_L1[k][3], f0[3]));
+        a = add4(a, ld4(KIFS_BUNNY_B1[k]));
+        f1[k] = add4(sin4(a), f0[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        V4 a = mat4_vec(KIFS_BUNNY_L2[k][0], f1[0]);
+        a = add4(a, mat4_vec(KIFS_BUNNY_L2[k][1], f1[1]));
+        a = add4(a, mat4_vec(KIFS_BUNNY_L2[k][2], f1[2]));
+        a = add4(a, mat4_vec(KIFS_BUNNY_L2[k][3], f1[3]));
+        a = add4(a, ld4(KIFS_BUNNY_B2[k]));
+        V4 sn = sin4(a);
+        f2[k] = V4{sn.x / 1.4f + f1[k].x, sn.y / 1.4f + f1[k].y, sn.z / 1.4f + f1[k].z,
+                   sn.w / 1.4f + f1[k].w};
+    }
+    float r = dot(f2[0], ld4(KIFS_BUNNY_OUT[0]));
+#pragma unroll
+    for (int k = 1; k < 4; ++k) r = r + dot(f2[k], ld4(KIFS_BUNNY_OUT[k]));
+    return r - 0.16f;
+}
+
+template <int PRIM>
+KIFS_DEV float kifs_sdf(const FrameParams& P, V3 p) {  // kifs.wgsl:139-155
+    if constexpr (PRIM == PRIM_SPHERE) {
+        return length(p) - 1.0f;
+    } else if constexpr (PRIM == PRIM_CYLINDER) {
+        V2 d{abs_(length(V2{p.x, p.y})) - 1.0f, abs_(p.z) - 2.0f};
+        V2 dm{max_(d.x, 0.0f), max_(d.y, 0.0f)};
+        return min_(max_(d.x, d.y), 0.0f) + length(dm);
+    } else if constexpr (PRIM == PRIM_BOX) {
+        V3 q{abs_(p.x) - 1.0f, abs_(p.y) - 1.0f, abs_(p.z) - 1.0f};
+        V3 qm{max_(q.x, 0.0f), max_(q.y, 0.0f), max_(q.z, 0.0f)};
+        return length(qm) + min_(max_(q.x, max_(q.y, q.z)), 0.0f);
+    } else if constexpr (PRIM == PRIM_TORUS) {
+        V2 q{length(V2{p.x, p.y}) - 1.0f, p.z};
+        return length(q) - 0.3f;
+    } else if constexpr (PRIM == PRIM_SIERPINSKI) {
+        return sierpinski_sdf(P, p);
+    } else if constexpr (PRIM == PRIM_BUNNY) {
+        return bunny_sdf(p);
+    } else {
+        return 1.0f;
+    }
+}
+
+template <int PRIM>
+KIFS_DEV V3 kifs_normal(const FrameParams& P, V3 p) {  // kifs.wgsl:157-167
+    const float h = P.epsilon;
+    float dx = kifs_sdf<PRIM>(P, V3{p.x + h, p.y + 0.0f, p.z + 0.0f}) -
+               kifs_sdf<PRIM>(P, V3{p.x - h, p.y - 0.0f, p.z - 0.0f});
+    float dy = kifs_sdf<PRIM>(P, V3{p.x + 0.0f, p.y + h, p.z + 0.0f}) -
+               kifs_sdf<PRIM>(P, V3{p.x - 0.0f, p.y - h, p.z - 0.0f});
+    float dz = kifs_sdf<PRIM>(P, V3{p.x + 0.0f, p.y + 0.0f, p.z + h}) -
+               kifs_sdf<PRIM>(P, V3{p.x - 0.0f, p.y - 0.0f, p.z - h});
+    return normalize(V3{dx, dy, dz});
+}
+
+template <int GROUP, int PRIM>
+KIFS_DEV float scene_sdf(const FrameParams& P, V3 p) {
+    if constexpr (GROUP == GROUP_JULIA) return julia_sdf(P, p);
+    else if constexpr (GROUP == GROUP_GENJULIA) return genjulia_sdf(P, p);
+    else return kifs_sdf<PRIM>(P, p);
+}
+
+template <int GROUP, int PRIM>
+KIFS_DEV V3 scene_normal(const FrameParams& P, V3 p) {
+    if constexpr (GROUP == GROUP_JULIA) return julia_normal(P, p);
+    else if constexpr (GROUP == GROUP_GENJULIA) return genjulia_normal(P, p);
+    else return kifs_normal<PRIM>(P, p);
+}
+
+// ---- fs_main: pixel -> ray (entry.wgsl:49-59) ---------------------------------------
+KIFS_DEV V3 ray_direction(const FrameParams& P, int x, int y) {
+    float px = float(x) + 0.5f, py = float(y) + 0.5f;  // fragment centre, y = 0 at the top
+    float uvx = (2.0f * px) / P.height - P.aspect;
+    float uvy = (2.0f * py) / P.height - 1.0f;
+    V3 d{(uvx * P.m1.x - uvy * P.m2.x) - P.m0.x, (uvx * P.m1.y - uvy * P.m2.y) - P.m0.y,
+         (uvx * P.m1.z - uvy * P.m2.z) - P.m0.z};
+    return normalize(d);
+}
+
+// ---- raymarch (entry.wgsl:6-29), wave64 form ------------------------------------------
+// Lanes march in lock step; a lane drops out on hit, on i == max_iterations or on
+// t >= max_distance.  The loop leaves as soon as __ballot says no lane is still
+// marching (wave-level early ray termination); normals are evaluated once, after
+// the loop, for the lanes that hit, so that divergent work is bunched together.
+template <int GROUP, int PRIM>
+KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
+    float t = 0.0f;
+    V3 p = P.origin;
+    int i = 0;
+    bool hit = false;
+    bool marching = valid && (i < P.max_iterations) && (t < P.max_distance);
+    while (__ballot(marching) != 0ull) {
+        if (marching) {
+            float d = scene_sdf<GROUP, PRIM>(P, p);
+            if (d < P.epsilon) {
+                hit = true;
+                marching = false;
+            } else {
+                t = t + d;
+                p = V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                       fmaf_(t, dir.z, P.origin.z)};
+                ++i;
+                marching = (i < P.max_iterations) && (t < P.max_distance);
+            }
+        }
+    }
+    V3 colour = P.background_color;
+    if (hit) {
+        V3 n = scene_normal<GROUP, PRIM>(P, p);
+        float ndl = (n.x + n.y) + n.z;  // dot(n, (1,1,1)): the light is not normalised (:17)
+        float diffuse = fmaf_(0.9f, clamp_(ndl, 0.0f, 1.0f), 0.1f);
+        colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
+                    diffuse * P.fractal_color.z};
+    }
+    if (P.is_heatmap) {
+        float f = float(i) / float(P.max_iterations);
+        colour = V3{f * P.fractal_color.x, f * P.fractal_color.y, f * P.fractal_color.z};
+    }
+    return colour;
+}
+
+}  // namespace kifs

@@ -1,0 +1,305 @@
+"""Host-side mirror of the reference's scene model and `GraphicState`, over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference so that tests read
+like the reference's own (paths under src/ of LesbianLemon/kifs-raymarching):
+
+  FractalGroup, PrimitiveShape          data/scene.rs:4-45
+  ScreenData, CameraData, GuiData       data.rs:51-160   (+ .into_buffer_data())
+  GraphicState                          render/graphics.rs:25-326
+      update_screen_data / zoom_camera / rotate_camera / update_options / render
+
+All arithmetic happens in the library (C++ host model, HIP kernels); this file only
+moves bytes.  PyTorch, when used, is plumbing: tensors give device memory and streams.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from enum import IntEnum
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CameraDataC, CameraUniform, GuiDataC, KifsError, OptionsUniform,
+                   ScreenUniform, check, lib)
+
+ENCODE_UNORM = _lib.ENCODE_UNORM
+ENCODE_SRGB = _lib.ENCODE_SRGB
+
+
+class FractalGroup(IntEnum):  # data/scene.rs:4-11
+    KaleidoscopicIFS = 0
+    JuliaSet = 1
+    GeneralizedJuliaSet = 2
+
+    @classmethod
+    def from_id(cls, i):
+        try:
+            return cls(i)
+        except ValueError:
+            return None
+
+
+class PrimitiveShape(IntEnum):  # data/scene.rs:35-45
+    Sphere = 0
+    Cylinder = 1
+    Box = 2
+    Torus = 3
+    SierpinskiTetrahedron = 4
+    Bunny = 5
+
+    @classmethod
+    def from_id(cls, i):
+        try:
+            return cls(i)
+        except ValueError:
+            return None
+
+
+@dataclass
+class ScreenData:  # data.rs:51-55
+    width: int = 0
+    height: int = 0
+
+    def into_buffer_data(self) -> ScreenUniform:  # data.rs:66-81
+        u = ScreenUniform()
+        check(lib.kifs_host_screen(self.width, self.height, C.byref(u)), "ScreenData")
+        return u
+
+
+@dataclass
+class CameraData:  # data.rs:83-113
+    origin_distance: float = 5.0
+    min_distance: float = 2.0
+    phi: float = 0.0    # angles.0
+    theta: float = 0.0  # angles.1
+
+    def _c(self) -> CameraDataC:
+        return CameraDataC(self.origin_distance, self.min_distance, self.phi, self.theta)
+
+    def _take(self, c: CameraDataC):
+        self.origin_distance, self.min_distance = c.origin_distance, c.min_distance
+        self.phi, self.theta = c.phi, c.theta
+
+    def camera_matrix(self) -> np.ndarray:
+        """3x3, element [r, c]; columns are the camera basis (data.rs:91-98)."""
+        m = (C.c_float * 9)()
+        c = self._c()
+        lib.kifs_host_camera_matrix(C.byref(c), m)
+        return np.array(m[:], dtype=np.float32).reshape(3, 3).T.copy()
+
+    def into_buffer_data(self) -> CameraUniform:  # data.rs:115-129
+        u = CameraUniform()
+        c = self._c()
+        check(lib.kifs_host_camera(C.byref(c), C.byref(u)), "CameraData")
+        return u
+
+
+@dataclass
+class GuiData:  # data.rs:131-160 (defaults = GuiData::default)
+    max_iterations: int = 256
+    max_distance: float = 1000.0
+    epsilon: float = 0.0001
+    fractal_color: tuple = (200, 200, 200)
+    background_color: tuple = (0, 0, 0)
+    is_heatmap: bool = False
+    fractal_group: FractalGroup = FractalGroup.KaleidoscopicIFS
+    primitive_shape: PrimitiveShape = PrimitiveShape.Sphere
+    power: float = 2.0
+    constant: tuple = (-0.1, 0.6, 0.9, -0.3)
+
+    def into_buffer_data(self) -> OptionsUniform:
+        """OptionsData::from(GuiData).into_buffer_data() (data.rs:176-220)."""
+        g = GuiDataC()
+        g.max_iterations = int(self.max_iterations)
+        g.max_distance = self.max_distance
+        g.epsilon = self.epsilon
+        g.fractal_color = (C.c_uint8 * 3)(*self.fractal_color)
+        g.background_color = (C.c_uint8 * 3)(*self.background_color)
+        g.is_heatmap = 1 if self.is_heatmap else 0
+        g.fractal_group = int(self.fractal_group)
+        g.primitive_shape = int(self.primitive_shape)
+        g.power = self.power
+        g.constant = (C.c_float * 4)(*self.constant)
+        u = OptionsUniform()
+        check(lib.kifs_host_options(C.byref(g), C.byref(u)), "GuiData")
+        return u
+
+
+def uniform_bytes(u) -> bytes:
+    """`bytemuck::bytes_of` of a uniform struct."""
+    return bytes(memoryview(u).cast("B"))
+
+
+def _device_pointer(obj):
+    if hasattr(obj, "data_ptr"):  # torch.Tensor
+        return int(obj.data_ptr())
+    return int(obj)
+
+
+class GraphicState:
+    """render/graphics.rs:25-37.  Owns one library context bound to one HIP device."""
+
+    def __init__(self, device: int = 0, screen_data: ScreenData = None,
+                 camera_data: CameraData = None, gui_data: GuiData = None):
+        st = C.c_int(0)
+        self._ctx = lib.kifs_create(device, C.byref(st))
+        if not self._ctx:
+            raise KifsError(st.value, f"kifs_create(device={device})")
+        self.device = device
+        self.screen_data = ScreenData()
+        self.camera_data = camera_data or CameraData()   # graphics.rs:194 CameraData::default
+        self.gui_data = gui_data or GuiData()            # graphics.rs:200 GuiData::default
+        self.camera_rotatable = False                    # graphics.rs:229
+        self.iters = (100, 10, 10)
+        self._upload_camera()
+        self.update_options(self.gui_data)
+        if screen_data is not None:
+            self.update_screen_data(screen_data)
+
+    # -- lifetime -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib.kifs_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- uniform updates (graphics.rs:262-308) ---------------------------------------
+    def update_screen_data(self, new_screen_data: ScreenData):
+        u = new_screen_data.into_buffer_data()
+        check(lib.kifs_set_screen(self._ctx, C.byref(u)), "update_screen_data")
+        self.screen_data = new_screen_data
+
+    def _upload_camera(self):
+        u = self.camera_data.into_buffer_data()
+        check(lib.kifs_set_camera(self._ctx, C.byref(u)), "camera")
+
+    def zoom_camera(self, distance: float):  # graphics.rs:268-278
+        c = self.camera_data._c()
+        check(lib.kifs_host_zoom(C.byref(c), distance))
+        self.camera_data._take(c)
+        self._upload_camera()
+
+    def rotate_camera(self, delta_phi: float, delta_theta: float):  # graphics.rs:280-302
+        if not self.camera_rotatable:
+            return
+        c = self.camera_data._c()
+        check(lib.kifs_host_rotate(C.byref(c), delta_phi, delta_theta))
+        self.camera_data._take(c)
+        self._upload_camera()
+
+    def mouse_motion(self, dx: float, dy: float):  # render.rs:255-270
+        if not self.camera_rotatable:
+            return
+        c = self.camera_data._c()
+        check(lib.kifs_host_mouse_motion(C.byref(c), dx, dy))
+        self.camera_data._take(c)
+        self._upload_camera()
+
+    def enable_camera_rotation(self):
+        self.camera_rotatable = True
+
+    def disable_camera_rotation(self):
+        self.camera_rotatable = False
+
+    def is_camera_rotatable(self):
+        return self.camera_rotatable
+
+    def set_camera(self, camera_data: CameraData):
+        self.camera_data = camera_data
+        self._upload_camera()
+
+    def update_options(self, new_options):
+        """Accepts GuiData (converted like render.rs:320-321) or a packed OptionsUniform."""
+        if isinstance(new_options, GuiData):
+            self.gui_data = new_options
+            u = new_options.into_buffer_data()
+        else:
+            u = new_options
+        check(lib.kifs_set_options(self._ctx, C.byref(u)), "update_options")
+        self._options_uniform = u
+
+    def set_raw_uniforms(self, screen: ScreenUniform = None, camera: CameraUniform = None,
+                         options: OptionsUniform = None):
+        """Upload pre-packed byte images (what a Rust host would pass)."""
+        if screen is not None:
+            check(lib.kifs_set_screen(self._ctx, C.byref(screen)), "set_screen")
+            self.screen_data = ScreenData(int(screen.width), int(screen.height))
+        if camera is not None:
+            check(lib.kifs_set_camera(self._ctx, C.byref(camera)), "set_camera")
+        if options is not None:
+            check(lib.kifs_set_options(self._ctx, C.byref(options)), "set_options")
+
+    def set_iters(self, sdf_iters=100, normal_iters=10, fold_iters=10):
+        check(lib.kifs_set_iters(self._ctx, sdf_iters, normal_iters, fold_iters), "set_iters")
+        self.iters = (sdf_iters, normal_iters, fold_iters)
+
+    # -- render (graphics.rs:310-325) -----------------------------------------------------
+    def render(self, out=None, y0: int = 0, y1: int = None, encode: int = ENCODE_SRGB,
+               pitch_bytes: int = None):
+        """Synchronous frame.  `out` None -> returns a (rows, W, 4) uint8 ndarray; an
+        ndarray -> filled in place; a torch CUDA tensor (uint8, rows*W*4) -> written on
+        the device."""
+        w, h = self.screen_data.width, self.screen_data.height
+        y1 = h if y1 is None else y1
+        rows = max(y1 - y0, 0)
+        if out is None:
+            out = np.empty((rows, w, 4), dtype=np.uint8)
+        pitch = pitch_bytes if pitch_bytes is not None else w * 4
+        if isinstance(out, np.ndarray):
+            assert out.dtype == np.uint8 and out.flags.c_contiguous
+            assert out.size >= rows * w * 4 or rows == 0
+            ptr = out.ctypes.data
+        else:
+            ptr = _device_pointer(out)
+        check(lib.kifs_render(self._ctx, ptr, pitch, y0, y1, encode), "render")
+        return out
+
+    def render_async(self, out, stream=None, y0: int = 0, y1: int = None,
+                     encode: int = ENCODE_SRGB, pitch_bytes: int = None):
+        """Enqueue on `stream` (int hipStream_t / torch stream / None = context stream)."""
+        w, h = self.screen_data.width, self.screen_data.height
+        y1 = h if y1 is None else y1
+        pitch = pitch_bytes if pitch_bytes is not None else w * 4
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        check(lib.kifs_render_async(self._ctx, stream, _device_pointer(out), pitch, y0, y1,
+                                    encode), "render_async")
+
+    def last_kernel_ms(self) -> float:
+        return float(lib.kifs_last_kernel_ms(self._ctx))
+
+    def synchronize(self):
+        check(lib.kifs_synchronize(self._ctx), "synchronize")
+
+    # -- point evaluation (parity tooling) -------------------------------------------------
+    def eval_points(self, points, want_normals=True):
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        n = pts.shape[0]
+        sdf = np.empty(n, dtype=np.float32)
+        nrm = np.empty((n, 3), dtype=np.float32) if want_normals else None
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+        check(lib.kifs_eval_points(self._ctx, fp(pts), n, fp(sdf), fp(nrm)), "eval_points")
+        return sdf, nrm
+
+    def eval_math(self, fn: int, x, param: float = 0.0):
+        xs = np.ascontiguousarray(x, dtype=np.float32).ravel()
+        out = np.empty_like(xs)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        check(lib.kifs_eval_math(self._ctx, fn, fp(xs), param, fp(out), xs.size), "eval_math")
+        return out
+
+
+def band_range(height: int, rank: int, world: int):
+    y0, y1 = C.c_int(), C.c_int()
+    check(lib.kifs_band_range(height, rank, world, C.byref(y0), C.byref(y1)), "band_range")
+    return y0.value, y1.value
