@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the raymarching hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one frame of the workload: one launch of the HIP render kernel over the
+frame (N = 1) or over this rank's row band followed by the RCCL gather of the bands into
+rank 0's frame (N > 1, one process per GPU, launched by torch.distributed.run).  The
+default workload is BASELINE.json's metric configuration: 1920x1080 quaternion-Julia,
+256 march steps, 12 SDF iterations.  Rank 0 prints ONE JSON line.
+
+There are no HBM-resident inputs beyond the 156 uniform bytes; the output frame lives in
+HBM (torch tensor) and is written by the kernel.  `roofline` prices the dominant kernel
+against the HBM-write roofline the north star mandates (4 algorithmic bytes per pixel);
+`cpu_baseline` times the CPU oracle (the stand-in for the reference's wgpu path, which
+cannot run here) on the host cores -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "Mpixels/s at 1920x1080, 256 march steps, 12 SDF iters; %HBM-peak"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default=None, help="name in kifs_raymarching_amd.configs.WORKLOADS")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="wall-clock budget of the cpu_baseline sample (0 disables it)")
+    ap.add_argument("--encode", type=int, default=1, help="1 = sRGB target (reference default), 0 = UNORM")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, seconds):
+    """Times the CPU oracle on whole frames of the same workload for ~`seconds`."""
+    import oracle as O
+    import kifs_raymarching_amd as K
+
+    ub = K.uniform_bytes
+    s = O.from_bytes(O.Screen, ub(w.screen.into_buffer_data()))
+    c = O.from_bytes(O.Camera, ub(w.camera.into_buffer_data()))
+    o = O.from_bytes(O.Options, ub(w.gui.into_buffer_data()))
+    it = O.iters(*w.iters)
+    cores = len(os.sched_getaffinity(0))
+    # bound the sample: time a slice first, then whole frames while the budget lasts
+    rows = max(8, w.screen.height // 16)
+    y0 = (w.screen.height - rows) // 2
+    t = time.perf_counter()
+    O.render(s, c, o, it, y0=y0, y1=y0 + rows, nthreads=cores)
+    slice_s = time.perf_counter() - t
+    est_frame = slice_s * w.screen.height / rows  # centre rows are the heavy ones: upper bound
+    if est_frame > seconds:  # a frame does not fit the budget: sample centred bands only
+        frames, px, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            O.render(s, c, o, it, y0=y0, y1=y0 + rows, nthreads=cores)
+            px += rows * w.screen.width
+            frames += 1
+        dt = time.perf_counter() - t0
+        sample = f"{frames} x centre band of {rows} rows of the {w.screen.width}x{w.screen.height} frame"
+    else:
+        frames, t0 = 0, time.perf_counter()
+        while frames < 1 or time.perf_counter() - t0 < seconds:
+            O.render(s, c, o, it, nthreads=cores)
+            frames += 1
+        dt = time.perf_counter() - t0
+        px = frames * w.pixels
+        sample = f"{frames} full {w.screen.width}x{w.screen.height} frames in {dt:.1f} s"
+    return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": sample + f", C oracle ({O.lib()._variant}), {cores} threads"}
+
+
+def pmc_traffic(workload_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass, if one exists."""
+    p = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        rec = json.loads(p.read_text()).get(workload_key)
+        return rec["hbm_bytes_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import kifs_raymarching_amd as K
+    from kifs_raymarching_amd.bands import BandFrame
+    from kifs_raymarching_amd.configs import HEADLINE, WORKLOADS
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run "
+                     "(one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    key = args.workload or HEADLINE
+    w = WORKLOADS[key]
+    W, H = w.screen.width, w.screen.height
+    gs = K.GraphicState(local_rank, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
+    gs.set_iters(*w.iters)
+    # Everything (kernel launches, events, the RCCL gather's stream dependencies) runs on
+    # one dedicated non-default stream, made current for the whole benchmark.
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    bf = BandFrame(W, H, rank, world, device)
+
+    def render_band(out, y0, y1):
+        gs.render_async(out, stream=stream, y0=y0, y1=y1, encode=args.encode)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for k in range(args.warmup):
+        bf.step(k, render_band)
+    bf.wait_all()
+    torch.cuda.synchronize()
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for k in range(args.steps):
+        bf.step(k, render_band)
+    ev1.record(stream)
+    bf.wait_all()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tk = torch.tensor([dev_ms], dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(tk) for _ in range(world)]
+        dist.all_gather(gathered, tk)
+        per_rank_ms = [float(x.item()) / args.steps for x in gathered]
+    else:
+        per_rank_ms = [dev_ms / args.steps]
+
+    if rank == 0:
+        mpix = W * H * args.steps / elapsed / 1e6
+        rows0 = bf.y1 - bf.y0
+        launch_s = dev_ms / 1e3 / args.steps
+        alg_bytes = 4.0 * W * rows0  # 4 B written per pixel, 0 read
+        achieved = alg_bytes / launch_s / 1e9
+        out = {
+            "metric": METRIC,
+            "value": round(mpix, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": key, "description": w.name, "width": W, "height": H,
+                       "max_iterations": w.gui.max_iterations, "sdf_iters": w.iters[0],
+                       "normal_iters": w.iters[1], "fold_iters": w.iters[2],
+                       "encode": "srgb8" if args.encode else "unorm8",
+                       "parallelism": "1 GPU, one launch per frame" if world == 1 else
+                       f"{world} row bands, one process per GPU, RCCL p2p gather to rank 0"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": pmc_traffic(key) if world == 1 else None,
+                         "kernel": "render_kernel", "kernel_ms": round(launch_s * 1e3, 5),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "per_rank_kernel_ms": [round(x, 5) for x in per_rank_ms],
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    gs.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

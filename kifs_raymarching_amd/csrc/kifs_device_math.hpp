@@ -183,7 +183,7 @@ KIFS_DEV float cos_kernel(float r) {
 }
 
 KIFS_DEV float sin_(float x) {
-    if (!(abs_(x) < 3.0e38f)) return x - x;
+    if (!(abs_(x) <= 1048576.0f)) return x - x;
     float r;
     int q = reduce_pio2(x, r);
     float s = (q & 1) ? cos_kernel(r) : sin_kernel(r);
@@ -191,7 +191,7 @@ KIFS_DEV float sin_(float x) {
 }
 
 KIFS_DEV float cos_(float x) {
-    if (!(abs_(x) < 3.0e38f)) return x - x;
+    if (!(abs_(x) <= 1048576.0f)) return x - x;
     float r;
     int q = reduce_pio2(x, r);
     float c = (q & 1) ? sin_kernel(r) : cos_kernel(r);

@@ -272,6 +272,11 @@ class GraphicState:
         pitch = pitch_bytes if pitch_bytes is not None else w * 4
         if stream is not None and hasattr(stream, "cuda_stream"):
             stream = stream.cuda_stream
+            if not stream:
+                # the C ABI reads a null hipStream_t as "the context's own stream"; the legacy
+                # default stream has handle 0 and would silently end up there
+                raise ValueError("render_async: pass a non-default torch.cuda.Stream "
+                                 "(the null stream handle selects the context's stream)")
         check(lib.kifs_render_async(self._ctx, stream, _device_pointer(out), pitch, y0, y1,
                                     encode), "render_async")
 

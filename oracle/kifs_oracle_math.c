@@ -166,7 +166,7 @@ static inline float cos_kernel(float r) {
 }
 
 float kor_sinf(float x) {
-    if (!(fabsf(x) < 3.0e38f)) return x - x; /* inf, NaN -> NaN */
+    if (!(fabsf(x) <= 1048576.0f)) return x - x; /* beyond 2^20 the 3-term reduction is meaningless: finite -> 0, inf/NaN -> NaN */
     float r;
     int q = reduce_pio2(x, &r);
     float s = (q & 1) ? cos_kernel(r) : sin_kernel(r);
@@ -174,7 +174,7 @@ float kor_sinf(float x) {
 }
 
 float kor_cosf(float x) {
-    if (!(fabsf(x) < 3.0e38f)) return x - x;
+    if (!(fabsf(x) <= 1048576.0f)) return x - x;
     float r;
     int q = reduce_pio2(x, &r);
     float c = (q & 1) ? sin_kernel(r) : cos_kernel(r);

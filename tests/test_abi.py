@@ -1,0 +1,120 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/kifs_hip.h
+declares; argument checking and the GPU-free entry points behave as documented."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "kifs_hip.h").read_text()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(kifs_\w+)\s*\(", body, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("kifs_create", "kifs_destroy", "kifs_set_screen", "kifs_set_camera",
+                 "kifs_set_options", "kifs_set_iters", "kifs_render", "kifs_render_async",
+                 "kifs_band_range", "kifs_last_kernel_ms", "kifs_strerror", "kifs_host_camera",
+                 "kifs_host_options", "kifs_host_screen", "kifs_eval_points", "kifs_eval_math"):
+        assert must in names
+    assert len(names) >= 25
+
+
+def test_library_exports_every_declared_symbol(kifs):
+    from kifs_raymarching_amd._lib import LIB_PATH, SIGNATURES
+    raw = C.CDLL(str(LIB_PATH))
+    for name in declared_functions():
+        assert hasattr(raw, name), f"{name} declared in kifs_hip.h but not exported"
+        assert name in SIGNATURES, f"{name} has no ctypes signature in _lib.py"
+    assert set(SIGNATURES) == set(declared_functions())
+
+
+def test_header_compiles_as_c_and_sizes_match(tmp_path):
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "kifs_hip.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(KifsScreenUniform),'
+                   'sizeof(KifsCameraUniform), sizeof(KifsOptionsUniform),'
+                   'offsetof(KifsCameraUniform, matrix), offsetof(KifsOptionsUniform, constant),'
+                   'offsetof(KifsOptionsUniform, is_heatmap));return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{ROOT / 'include'}",
+                    str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["12", "64", "80", "16", "64", "44"]
+
+
+def test_strerror_and_version(kifs):
+    from kifs_raymarching_amd._lib import lib
+    assert lib.kifs_abi_version() == 1
+    assert lib.kifs_strerror(0) == b"ok"
+    msgs = {lib.kifs_strerror(i) for i in range(8)}
+    assert len(msgs) == 8 and lib.kifs_strerror(99) == b"unknown status"
+
+
+def test_band_range(kifs):
+    from kifs_raymarching_amd._lib import lib
+    for h, world in ((1080, 8), (4096, 8), (4320, 8), (1080, 7), (5, 8), (0, 3), (1, 1)):
+        ranges = [kifs.band_range(h, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == h
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+    assert kifs.band_range(1080, 3, 8) == (405, 540)
+    y0, y1 = C.c_int(), C.c_int()
+    assert lib.kifs_band_range(10, 3, 3, C.byref(y0), C.byref(y1)) == 7  # BAD_ARG
+    assert lib.kifs_band_range(10, 0, 0, C.byref(y0), C.byref(y1)) == 7
+
+
+def test_null_and_bad_arguments_do_not_crash(kifs):
+    from kifs_raymarching_amd._lib import lib
+    assert lib.kifs_set_screen(None, None) == 7
+    assert lib.kifs_set_camera(None, None) == 7
+    assert lib.kifs_set_options(None, None) == 7
+    assert lib.kifs_set_iters(None, 1, 1, 1) == 7
+    assert lib.kifs_render(None, None, 0, 0, 0, 1) == 7
+    assert lib.kifs_render_async(None, None, None, 0, 0, 0, 1) == 7
+    assert lib.kifs_synchronize(None) == 7
+    assert lib.kifs_last_kernel_ms(None) < 0
+    lib.kifs_destroy(None)  # no-op
+    assert lib.kifs_host_screen(0, 5, None) == 7
+    assert lib.kifs_host_camera(None, None) == 7 and lib.kifs_host_options(None, None) == 7
+
+
+def test_create_reports_missing_device(kifs):
+    """On a box without a GPU kifs_create fails with NO_DEVICE (never a silent fallback);
+    with a GPU an out-of-range ordinal fails the same way."""
+    from kifs_raymarching_amd._lib import lib
+    st = C.c_int(-1)
+    ctx = lib.kifs_create(4096, C.byref(st))
+    assert not ctx and st.value == 1
+    with pytest.raises(kifs.KifsError) as e:
+        kifs.GraphicState(4096)
+    assert e.value.status == 1
+
+
+def test_package_fails_loudly_without_the_library(tmp_path):
+    """Importing the package with libkifs_hip.so absent must raise, not fall back."""
+    import shutil
+    import subprocess
+    import sys
+    pkg = tmp_path / "kifs_raymarching_amd"
+    shutil.copytree(ROOT / "kifs_raymarching_amd", pkg,
+                    ignore=shutil.ignore_patterns("*.so", "csrc", "__pycache__"))
+    r = subprocess.run([sys.executable, "-c", "import kifs_raymarching_amd"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "libkifs_hip.so" in r.stderr and "no CPU fallback" in r.stderr.replace("\n", " ")
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under kifs_raymarching_amd/ may reference it."""
+    for p in (ROOT / "kifs_raymarching_amd").rglob("*"):
+        if p.suffix in (".py", ".cpp", ".hip", ".hpp", ".h") or p.name == "Makefile":
+            text = p.read_text()
+            assert "oracle" not in text.lower(), p

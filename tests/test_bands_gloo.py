@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: world_size 2 and 3 over the gloo backend.  Each rank renders its
+row band (the CPU oracle stands in for the GPU kernel -- same band contract: global pixel
+coordinates, rows [y0, y1)) into the BandFrame buffers; the grouped point-to-point gather
+must assemble, on rank 0, a frame identical to the single-process frame, for several
+pipelined frames with double buffering."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, width, height, frames, outdir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from kifs_raymarching_amd.bands import BandFrame
+
+        sc = O.screen_uniform(width, height)
+        opt = O.options_from_gui(fractal_group=1, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=48)
+        it = O.iters(8, 4, 4)
+        bf = BandFrame(width, height, rank, world, "cpu")
+        assert bf.ranges[0][0] == 0 and bf.ranges[-1][1] == height
+
+        def make_render(k):
+            cam = O.camera_uniform(3.0, 0.3 * k, 0.1)
+
+            def render_band(out, y0, y1):
+                out.copy_(torch.from_numpy(O.render(sc, cam, opt, it, y0=y0, y1=y1, nthreads=1)))
+            return render_band
+
+        results = []
+        for k in range(frames):
+            bf.step(k, make_render(k))
+            if k >= 1:  # consume frame k-1 while frame k is in flight (double buffering)
+                bf.wait(k - 1)
+                if rank == 0:
+                    results.append(bf.frame(k - 1).clone().numpy())
+        bf.wait_all()
+        if rank == 0:
+            results.append(bf.frame(frames - 1).clone().numpy())
+            np.save(os.path.join(outdir, "gathered.npy"), np.stack(results))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 40), (3, 41)])
+def test_band_gather_equals_single_frame(world, height, tmp_path, oracle):
+    width, frames = 48, 4
+    mp.spawn(_worker, args=(world, _free_port(), width, height, frames, str(tmp_path)),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    sc = oracle.screen_uniform(width, height)
+    opt = oracle.options_from_gui(fractal_group=1, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=48)
+    for k in range(frames):
+        want = oracle.render(sc, oracle.camera_uniform(3.0, 0.3 * k, 0.1), opt, oracle.iters(8, 4, 4))
+        assert (got[k] == want).all(), f"frame {k} differs"
+        assert (want != want[0, 0]).any()
+
+
+def test_bandframe_single_rank_needs_no_process_group(kifs):
+    from kifs_raymarching_amd.bands import BandFrame
+    bf = BandFrame(16, 9, 0, 1, "cpu")
+    calls = []
+    bf.step(0, lambda out, y0, y1: calls.append((tuple(out.shape), y0, y1)))
+    bf.wait_all()
+    assert calls == [((9, 16, 4), 0, 9)] and bf.frame(0).shape == (9, 16, 4)
+    with pytest.raises(ValueError):
+        BandFrame(0, 9, 0, 1, "cpu")

@@ -1,0 +1,164 @@
+"""GPU behaviour of the C ABI itself: status codes, host/device destinations, pitch,
+bands, async launches on a caller stream, and the BASELINE configurations at full size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import diff_report, gpu_frame, oracle_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def test_render_before_configuration_is_an_error(kifs):
+    from kifs_raymarching_amd._lib import lib
+    st = C.c_int()
+    ctx = lib.kifs_create(0, C.byref(st))
+    assert ctx and st.value == 0
+    try:
+        buf = np.zeros(64, dtype=np.uint8)
+        assert lib.kifs_render(ctx, buf.ctypes.data, 16, 0, 1, 1) == 4  # UNCONFIGURED
+        s = kifs.ScreenData(4, 4).into_buffer_data()
+        assert lib.kifs_set_screen(ctx, C.byref(s)) == 0
+        assert lib.kifs_render(ctx, buf.ctypes.data, 16, 0, 1, 1) == 4  # camera/options missing
+        bad = kifs.ScreenData(4, 4).into_buffer_data()
+        bad.width = 0.0
+        assert lib.kifs_set_screen(ctx, C.byref(bad)) == 3  # BAD_SIZE
+        bad.width = 4.5
+        assert lib.kifs_set_screen(ctx, C.byref(bad)) == 3
+        o = kifs.GuiData().into_buffer_data()
+        o.fractal_group_id = 3
+        assert lib.kifs_set_options(ctx, C.byref(o)) == 7  # FractalGroup::from_id -> None
+        assert lib.kifs_set_iters(ctx, -1, 0, 0) == 7
+        assert lib.kifs_last_kernel_ms(ctx) < 0
+    finally:
+        lib.kifs_destroy(ctx)
+
+
+def test_argument_checks_on_render(gs, kifs):
+    from kifs_raymarching_amd._lib import lib
+    gs.update_screen_data(kifs.ScreenData(32, 16))
+    gs.set_camera(kifs.CameraData())
+    gs.update_options(kifs.GuiData())
+    buf = np.zeros(32 * 16 * 4, dtype=np.uint8)
+    ctx = gs._ctx
+    assert lib.kifs_render(ctx, buf.ctypes.data, 32 * 4, 0, 16, 1) == 0
+    assert lib.kifs_render(ctx, buf.ctypes.data, 32 * 4, 0, 17, 1) == 7   # y1 > H
+    assert lib.kifs_render(ctx, buf.ctypes.data, 32 * 4, 5, 4, 1) == 7    # y0 > y1
+    assert lib.kifs_render(ctx, buf.ctypes.data, 32 * 4 - 4, 0, 16, 1) == 3  # pitch < 4W
+    assert lib.kifs_render(ctx, buf.ctypes.data, 32 * 4, 0, 16, 2) == 7   # unknown encode
+    assert lib.kifs_render(ctx, buf.ctypes.data, 32 * 4, 7, 7, 1) == 0    # empty band is fine
+    assert gs.last_kernel_ms() > 0
+
+
+def test_host_pitch_and_ragged_sizes(gs, kifs, oracle):
+    """Widths/heights that are not multiples of the 32x8 tile, and a padded host pitch."""
+    cam, gui = kifs.CameraData(origin_distance=3.0), kifs.GuiData(primitive_shape=kifs.PrimitiveShape.Torus)
+    for w, h in ((1, 1), (33, 9), (31, 7), (100, 3), (65, 130)):
+        screen = kifs.ScreenData(w, h)
+        want = oracle_frame(oracle, kifs, screen, cam, gui, (100, 10, 10))
+        got = gpu_frame(gs, screen, cam, gui, (100, 10, 10))
+        assert (got == want).all(), (w, h)
+        pitch = w * 4 + 24
+        raw = np.full(pitch * h, 0xAB, dtype=np.uint8)
+        gs.render(out=raw, pitch_bytes=pitch)
+        rows = raw.reshape(h, pitch)
+        assert (rows[:, :w * 4].reshape(h, w, 4) == want).all()
+        assert (rows[:, w * 4:] == 0xAB).all()  # padding untouched
+
+
+def test_bands_tile_the_frame(gs, kifs, oracle):
+    """SURVEY 8e on one GPU: N bands rendered one after another == the single frame."""
+    screen, cam = kifs.ScreenData(200, 135), kifs.CameraData(origin_distance=3.2, phi=0.4)
+    gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2))
+    full = gpu_frame(gs, screen, cam, gui, (12, 10, 10))
+    assert (full == oracle_frame(oracle, kifs, screen, cam, gui, (12, 10, 10))).all()
+    for world in (2, 3, 8):
+        parts = [gs.render(y0=a, y1=b) for a, b in (kifs.band_range(135, r, world) for r in range(world))]
+        assert (np.concatenate(parts) == full).all(), world
+
+
+def test_device_destination_and_async_stream(gs, kifs, oracle):
+    import torch
+    screen, cam = kifs.ScreenData(160, 90), kifs.CameraData()
+    gui = kifs.GuiData(primitive_shape=kifs.PrimitiveShape.SierpinskiTetrahedron)
+    want = oracle_frame(oracle, kifs, screen, cam, gui, (100, 10, 16))
+    host = gpu_frame(gs, screen, cam, gui, (100, 10, 16))
+    assert (host == want).all()
+    dev = torch.zeros((90, 160, 4), dtype=torch.uint8, device="cuda:0")
+    gs.render(out=dev)  # synchronous, device destination
+    assert (dev.cpu().numpy() == want).all()
+    s = torch.cuda.Stream()
+    dev2 = torch.zeros_like(dev)
+    with torch.cuda.stream(s):
+        gs.render_async(dev2, stream=s)
+        gs.render_async(dev2[45:], stream=s, y0=45, y1=90)  # overwrite the lower half again
+    s.synchronize()
+    assert (dev2.cpu().numpy() == want).all()
+    dev3 = torch.zeros_like(dev)
+    gs.render_async(dev3)  # context stream
+    gs.synchronize()
+    assert (dev3.cpu().numpy() == want).all()
+    with pytest.raises(ValueError):
+        gs.render_async(dev3, stream=torch.cuda.default_stream())
+
+
+def test_bandframe_on_gpu_world1(gs, kifs, oracle):
+    import torch
+    from kifs_raymarching_amd.bands import BandFrame
+    screen, cam = kifs.ScreenData(96, 54), kifs.CameraData()
+    gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2))
+    gpu_frame(gs, screen, cam, gui, (12, 10, 10))
+    bf = BandFrame(96, 54, 0, 1, "cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for k in range(3):
+            bf.step(k, lambda out, y0, y1: gs.render_async(out, stream=s, y0=y0, y1=y1))
+        bf.wait_all()
+    s.synchronize()
+    want = oracle_frame(oracle, kifs, screen, cam, gui, (12, 10, 10))
+    assert (bf.frame(2).cpu().numpy() == want).all()
+
+
+FULL = ["cfg2_julia_1080p", "cfg3_sierpinski_1080p", "ref_julia_1080p"]
+
+
+@pytest.mark.parametrize("key", FULL)
+def test_baseline_configs_full_size(key, gs, kifs, oracle):
+    """The 1080p BASELINE workloads, every pixel, against the oracle (multi-threaded)."""
+    from kifs_raymarching_amd.configs import WORKLOADS
+    w = WORKLOADS[key]
+    got = gpu_frame(gs, w.screen, w.camera, w.gui, w.iters)
+    want = oracle_frame(oracle, kifs, w.screen, w.camera, w.gui, w.iters)
+    rep = diff_report(got, want)
+    assert rep["mismatched_pixels"] == 0, rep
+    assert (want[..., 0] != want[0, 0, 0]).sum() > 10000
+
+
+def test_cfg4_4096_bands_and_symmetry_properties(gs, kifs, oracle):
+    """4096x4096 (config 4): eight 512-row bands equal the full frame; two bands are
+    checked against the oracle; untouched corners are exact background."""
+    from kifs_raymarching_amd.configs import WORKLOADS
+    w = WORKLOADS["cfg4_julia_4096"]
+    full = gpu_frame(gs, w.screen, w.camera, w.gui, w.iters)
+    assert full.shape == (4096, 4096, 4)
+    for r in range(8):
+        y0, y1 = kifs.band_range(4096, r, 8)
+        assert (y0, y1) == (512 * r, 512 * (r + 1))
+        assert (gs.render(y0=y0, y1=y1) == full[y0:y1]).all(), r
+    for y0, y1 in ((2040, 2056), (1400, 1408)):
+        want = oracle_frame(oracle, kifs, w.screen, w.camera, w.gui, w.iters, y0=y0, y1=y1)
+        assert (full[y0:y1] == want).all()
+    assert (full[:64, :64] == full[0, 0]).all() and (full[..., 3] == 255).all()
+
+
+def test_orbit_frames_match_oracle(gs, kifs, oracle):
+    """Config-5 style orbit (host camera scripting per graphics.rs:280-302), thumbnails."""
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg5_sierpinski_8k_orbit"]
+    screen = kifs.ScreenData(192, 108)
+    for k in (0, 17, 60, 119):
+        cam = orbit_camera(w, k)
+        got = gpu_frame(gs, screen, cam, w.gui, w.iters)
+        want = oracle_frame(oracle, kifs, screen, cam, w.gui, w.iters)
+        assert (got == want).all(), k
