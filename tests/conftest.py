@@ -26,10 +26,8 @@ def oracle():
 @pytest.fixture(scope="session")
 def kifs():
     """The product package; importing it loads libkifs_hip.so (no fallback)."""
-    lib_path = ROOT / "kifs_raymarching_amd" / "libkifs_hip.so"
-    if not lib_path.exists():
-        import __graft_entry__ as g
-        g.build()
+    import __graft_entry__ as g
+    g.build()  # no-op when libkifs_hip.so matches the recorded source hash
     import kifs_raymarching_amd as K
     return K
 
