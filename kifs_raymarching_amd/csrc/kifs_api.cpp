@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <vector>
 
 #include "../../include/kifs_hip.h"
 #include "kifs_internal.hpp"
@@ -26,8 +28,20 @@ static_assert(offsetof(KifsOptionsUniform, is_heatmap) == 44, "is_heatmap at 44"
 static_assert(offsetof(KifsOptionsUniform, power) == 56, "power at 56");
 static_assert(offsetof(KifsOptionsUniform, constant) == 64, "constant at 64");
 
+// Tile order tables are keyed by the geometry they were built for and kept on the
+// device; a context alternates between very few geometries (full frame, its band).
+struct TileTable {
+    int width = 0, height = 0, y0 = 0, y1 = 0;
+    uint32_t* d_order = nullptr;
+    uint32_t count = 0;
+    uint64_t last_use = 0;
+};
+constexpr int MAX_TILE_TABLES = 8;
+
 struct kifs_ctx {
     int device = 0;
+    TileTable tables[MAX_TILE_TABLES];
+    uint64_t use_clock = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float* d_srgb = nullptr;       // 256 thresholds
@@ -43,6 +57,14 @@ struct kifs_ctx {
 };
 
 namespace {
+
+// KIFS_DEBUG=1 prints the failing HIP call to stderr (status codes stay the contract).
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    static const bool verbose = std::getenv("KIFS_DEBUG") != nullptr;
+    if (verbose) std::fprintf(stderr, "kifs: %s failed: %s\n", what, hipGetErrorString(e));
+    return false;
+}
 
 struct DeviceGuard {  // make ctx's device current for the duration of a call
     int prev = -1;
@@ -98,6 +120,8 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->pitch_words = uint32_t(w);
     P->out = nullptr;
     P->srgb_table = c->d_srgb;
+    P->tile_order = nullptr;
+    P->tile_count = 0;
     return KIFS_OK;
 }
 
@@ -111,8 +135,60 @@ bool is_device_pointer(const void* p) {
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+// Order in which workgroups take tiles: nearest to the frame centre first (squared
+// distance of the tile centre, ties by row then column), so the long rays start first.
+// Tiles are TILE_W x TILE_H pixels; rows are counted from the top of the band.
+const TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
+    TileTable* slot = nullptr;
+    for (auto& t : c->tables) {
+        if (t.d_order && t.width == width && t.height == height && t.y0 == y0 && t.y1 == y1) {
+            t.last_use = ++c->use_clock;
+            return &t;
+        }
+        if (!slot || t.last_use < slot->last_use) slot = &t;
+    }
+    const int tx = (width + kifs::TILE_W - 1) / kifs::TILE_W;
+    const int ty = (y1 - y0 + kifs::TILE_H - 1) / kifs::TILE_H;
+    if (tx > 0xffff || ty > 0xffff) return nullptr;
+    struct Key { int64_t d2; uint32_t id; };
+    std::vector<Key> keys;
+    keys.reserve(size_t(tx) * ty);
+    for (int j = 0; j < ty; ++j)
+        for (int i = 0; i < tx; ++i) {
+            // doubled coordinates keep everything in integers
+            int64_t cx = int64_t(2 * i + 1) * kifs::TILE_W - width;
+            int64_t cy = int64_t(2 * j + 1) * kifs::TILE_H + 2 * int64_t(y0) - height;
+            keys.push_back({cx * cx + cy * cy, (uint32_t(j) << 16) | uint32_t(i)});
+        }
+    std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+        return a.d2 != b.d2 ? a.d2 < b.d2 : a.id < b.id;
+    });
+    std::vector<uint32_t> order(keys.size());
+    for (size_t k = 0; k < keys.size(); ++k) order[k] = keys[k].id;
+    // the slot being replaced may still be read by an enqueued launch: drain first
+    if (slot->d_order) {
+        hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize(before tile table eviction)");
+        hip_ok(hipFree(slot->d_order), "hipFree(tile order)");
+        slot->d_order = nullptr;
+    }
+    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&slot->d_order), order.size() * sizeof(uint32_t)),
+                "hipMalloc(tile order)"))
+        return nullptr;
+    if (!hip_ok(hipMemcpy(slot->d_order, order.data(), order.size() * sizeof(uint32_t),
+                          hipMemcpyHostToDevice), "hipMemcpy(tile order)")) {
+        (void)hipFree(slot->d_order);
+        slot->d_order = nullptr;
+        return nullptr;
+    }
+    slot->width = width; slot->height = height; slot->y0 = y0; slot->y1 = y1;
+    slot->count = uint32_t(order.size());
+    slot->last_use = ++c->use_clock;
+    return slot;
+}
+
 int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int y0, int y1,
             int encode) {
+    hip_ok(hipGetLastError(), "stale error before enqueue");
     if (!c->have_screen || !c->have_camera || !c->have_options) return KIFS_ERR_UNCONFIGURED;
     if (!dev_out) return KIFS_ERR_BAD_ARG;
     if (encode != KIFS_ENCODE_UNORM && encode != KIFS_ENCODE_SRGB) return KIFS_ERR_BAD_ARG;
@@ -129,9 +205,14 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
     P.encode = encode;
     P.pitch_words = uint32_t(pitch >> 2);
     P.out = reinterpret_cast<uint32_t*>(dev_out);
+    if (y1 == y0) return KIFS_OK;
+    const TileTable* tt = tile_table(c, P.width, h, y0, y1);
+    if (!tt) return KIFS_ERR_RUNTIME;
+    P.tile_order = tt->d_order;
+    P.tile_count = tt->count;
     hipError_t e = kifs::launch_render(P, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
-    return e == hipSuccess ? KIFS_OK : KIFS_ERR_RUNTIME;
+    return hip_ok(e, "render_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;
 }
 
 }  // namespace
@@ -189,6 +270,8 @@ void kifs_destroy(kifs_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& t : c->tables)
+        if (t.d_order) (void)hipFree(t.d_order);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_srgb) (void)hipFree(c->d_srgb);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -270,7 +353,7 @@ int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int enc
             if (c->d_scratch) (void)hipFree(c->d_scratch);
             c->d_scratch = nullptr;
             c->scratch_bytes = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&c->d_scratch), need) != hipSuccess)
+            if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_scratch), need), "hipMalloc(scratch)"))
                 return KIFS_ERR_RUNTIME;
             c->scratch_bytes = need;
         }
@@ -286,7 +369,7 @@ int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int enc
                              hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             return KIFS_ERR_RUNTIME;
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+    if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return KIFS_ERR_RUNTIME;
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) c->last_ms = ms;
     return KIFS_OK;

@@ -15,6 +15,10 @@ hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t pri
 hipError_t launch_eval_math(int fn, const float* in, float param, const float* srgb_table,
                             float* out, int n, hipStream_t stream);
 
+// Workgroup tile geometry of render_kernel (shared with the host-side tile ordering).
+constexpr int TILE_W = 32;
+constexpr int TILE_H = 8;
+
 // 256 sRGB thresholds: t[k] = smallest f32 whose ideal sRGB UNORM8 encoding is >= k.
 void build_srgb_thresholds(float t[256]);
 

@@ -8,9 +8,14 @@
 //     256-entry sRGB threshold table is staged into LDS once per workgroup.
 //   * Encoded pixels go through an LDS tile so that the global store is linear:
 //     every wave-level store instruction writes two full 128-byte row segments.
-//   * Consecutive blockIdx.x are horizontal neighbours and the dispatcher deals
-//     workgroups round-robin over the 8 XCDs, so the expensive tiles at the centre of
-//     the image spread evenly over the XCDs; there is no inter-workgroup data.
+//   * The frame's run time is set by its longest rays (a lone wave pays ~5 cycles per
+//     instruction whatever else the chip does), so workgroups take their tile from a
+//     host-built order table, nearest-to-the-image-centre first: the camera always looks
+//     at the world origin (data.rs:115-129), where every scene of the reference sits, so
+//     the rays that march longest start at t = 0 instead of behind thousands of cheap
+//     background tiles.  Neighbouring entries of the table are dealt round-robin over the
+//     8 XCDs by the dispatcher, which spreads the expensive centre evenly; there is no
+//     inter-workgroup data, so placement only affects speed.
 //
 // Replaces: vs_main + rasteriser + fs_main + ROP of the reference
 // (src/shaders/dependencies/entry.wgsl:35-59, src/render/graphics.rs:310-325,
@@ -20,8 +25,6 @@
 
 namespace kifs {
 
-constexpr int TILE_W = 32;
-constexpr int TILE_H = 8;
 constexpr int BLOCK = TILE_W * TILE_H;  // 256 threads = 4 waves
 
 template <int GROUP, int PRIM>
@@ -37,8 +40,11 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
     const int wave = tid >> 6, lane = tid & 63;
     const int lx = (wave << 3) | (lane & 7);
     const int ly = lane >> 3;
-    const int x = blockIdx.x * TILE_W + lx;
-    const int y = P.y0 + blockIdx.y * TILE_H + ly;
+    const uint32_t tile = P.tile_order[blockIdx.x];  // scalar load: uniform per workgroup
+    const int tile_x = int(tile & 0xffffu) * TILE_W;
+    const int tile_y = int(tile >> 16) * TILE_H;     // row offset within the band
+    const int x = tile_x + lx;
+    const int y = P.y0 + tile_y + ly;
     const bool valid = (x < P.width) && (y < P.y1);
 
     V3 colour{0.0f, 0.0f, 0.0f};
@@ -63,8 +69,8 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
 
     // store mapping: thread -> (tid & 31, tid >> 5): linear rows of 128 bytes
     const int sx = tid & (TILE_W - 1), sy = tid >> 5;
-    const int ox = blockIdx.x * TILE_W + sx;
-    const int oy = blockIdx.y * TILE_H + sy;  // row within the band
+    const int ox = tile_x + sx;
+    const int oy = tile_y + sy;  // row within the band
     if (ox < P.width && (P.y0 + oy) < P.y1)
         P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
 }
@@ -74,15 +80,13 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
 // primitive_id per SDF call (kifs.wgsl:139-155).  Here both are template parameters.
 template <int GROUP, int PRIM>
 static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
-    const int rows = P.y1 - P.y0;
-    dim3 grid((P.width + TILE_W - 1) / TILE_W, (rows + TILE_H - 1) / TILE_H);
-    hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), grid, dim3(BLOCK), 0, stream, P);
+    hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), dim3(P.tile_count), dim3(BLOCK), 0, stream, P);
     return hipGetLastError();
 }
 
 hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitive,
                          hipStream_t stream) {
-    if (P.y1 <= P.y0 || P.width <= 0) return hipSuccess;
+    if (P.y1 <= P.y0 || P.width <= 0 || P.tile_count == 0) return hipSuccess;
     switch (group) {
     case GROUP_JULIA: return launch_variant<GROUP_JULIA, 0>(P, stream);
     case GROUP_GENJULIA: return launch_variant<GROUP_GENJULIA, 0>(P, stream);

@@ -31,6 +31,8 @@ struct FrameParams {
     uint32_t pitch_words;               // output row pitch in 32-bit words
     uint32_t* out;                      // first row of the band
     const float* srgb_table;            // 256 thresholds, device memory
+    const uint32_t* tile_order;         // workgroup b renders tile (order[b] & 0xffff, order[b] >> 16)
+    uint32_t tile_count;
 };
 
 }  // namespace kifs

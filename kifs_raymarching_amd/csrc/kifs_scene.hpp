@@ -265,7 +265,14 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
     int i = 0;
     bool hit = false;
     bool marching = valid && (i < P.max_iterations) && (t < P.max_distance);
+    int trips = 0;  // wave-uniform count of loop trips
     while (__ballot(marching) != 0ull) {
+        // Long-marching waves are the frame's critical path: raise their issue priority as
+        // they age so that co-resident short waves never delay them.
+        if (trips == 24) __builtin_amdgcn_s_setprio(1);
+        else if (trips == 64) __builtin_amdgcn_s_setprio(2);
+        else if (trips == 128) __builtin_amdgcn_s_setprio(3);
+        ++trips;
         if (marching) {
             float d = scene_sdf<GROUP, PRIM>(P, p);
             if (d < P.epsilon) {
@@ -280,6 +287,7 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
             }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     V3 colour = P.background_color;
     if (hit) {
         V3 n = scene_normal<GROUP, PRIM>(P, p);
