@@ -7,6 +7,7 @@
 // CPU path: every entry point that produces pixels launches the HIP kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -89,6 +90,22 @@ int frame_dims(const kifs_ctx* c, int* w, int* h) {
     return KIFS_OK;
 }
 
+// Exact squared form of `norm > T` for norm = sqrtf(n2) (correctly rounded, monotone):
+// returns the largest binary32 v with sqrtf(v) <= T, so that norm > T  <=>  n2 > v.
+float squared_threshold(float T) {
+    if (T != T) return INFINITY;          // norm > NaN is never true
+    if (T < 0.0f) return -1.0f;           // every non-NaN norm (>= 0) exceeds a negative T
+    if (T == INFINITY) return INFINITY;
+    double sq = double(T) * double(T);
+    float v = sq >= double(FLT_MAX) ? FLT_MAX : float(sq);
+    while (v > 0.0f && std::sqrt(v) > T) v = std::nextafterf(v, -INFINITY);
+    for (;;) {
+        float up = std::nextafterf(v, INFINITY);
+        if (up != INFINITY && std::sqrt(up) <= T) v = up; else break;
+    }
+    return v;
+}
+
 int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     int w, h;
     int st = frame_dims(c, &w, &h);
@@ -113,6 +130,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->sdf_iters = c->sdf_iters;
     P->normal_iters = c->normal_iters;
     P->fold_iters = c->fold_iters;
+    P->bound_n2 = squared_threshold(2.0f + o.epsilon);
     P->width = w;
     P->y0 = 0;
     P->y1 = h;

@@ -39,6 +39,12 @@ KIFS_DEV float clamp_(float e, float lo, float hi) { return min_(max_(e, lo), hi
 KIFS_DEV float qnan() { return from_bits(0x7fc00000u); }
 KIFS_DEV float pinf() { return from_bits(0x7f800000u); }
 
+// Packed f32: one v_pk_* instruction does two lanes' worth of work per thread and costs a
+// lone wave the same ~5 cycles as a scalar-f32 VALU op (tools/microbench/issue_cost.hip),
+// so on the latency-bound tail of a frame it halves the critical path of whatever packs.
+typedef float F2 __attribute__((ext_vector_type(2)));
+KIFS_DEV F2 pk_fma(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // dot products as fma chains, first component first
 KIFS_DEV float dot(V2 a, V2 b) { return fmaf_(a.y, b.y, a.x * b.x); }
 KIFS_DEV float dot(V3 a, V3 b) { return fmaf_(a.z, b.z, fmaf_(a.y, b.y, a.x * b.x)); }
@@ -92,7 +98,27 @@ KIFS_DEV float log_reduce(float x, int& e) {
     return m;
 }
 
-KIFS_DEV float log_(float x) {
+// log of a positive, finite, normal x: the whole function for almost every call.
+KIFS_DEV float log_normal(float x) {
+    uint32_t ix = bits(x);
+    int e = int(ix >> 23) - 126;
+    float m = from_bits((ix & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float y = (log_poly(m) * m) * z;
+    float fe = float(e);
+    y = fmaf_(fe, -2.12194440e-4f, y);
+    y = fmaf_(-0.5f, z, y);
+    float r = m + y;
+    return fmaf_(fe, 0.693359375f, r);
+}
+
+KIFS_DEV float log_general(float x) {
     if (x != x) return x + x;
     if (x < 0.0f) return qnan();
     if (x == 0.0f) return -pinf();
@@ -106,6 +132,14 @@ KIFS_DEV float log_(float x) {
     y = fmaf_(-0.5f, z, y);
     float r = m + y;
     return fmaf_(fe, 0.693359375f, r);
+}
+
+// Zero, denormal, negative, infinite and NaN arguments are rare: the wave takes the general
+// routine (identical results on normal inputs) only if some lane holds one.
+KIFS_DEV float log_(float x) {
+    const bool ordinary = (x >= 1.17549435e-38f) && (x <= 3.40282347e38f);
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return log_general(x);
+    return log_normal(x);
 }
 
 KIFS_DEV float log2_(float x) {

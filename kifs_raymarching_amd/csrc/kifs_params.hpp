@@ -26,6 +26,9 @@ struct FrameParams {
     float power;
     V4 c;
     int sdf_iters, normal_iters, fold_iters;  // julia.wgsl:2-3, kifs.wgsl:72 made parameters
+    // Largest f32 v with sqrt(v) <= 2 + epsilon: `length(p) > 2 + epsilon` (julia.wgsl:8) is
+    // exactly `dot(p,p) > bound_n2` because correctly rounded sqrt is monotone.
+    float bound_n2;
     int width, y0, y1;                  // frame width, row band [y0, y1)
     int encode;                         // KifsEncode
     uint32_t pitch_words;               // output row pitch in 32-bit words

@@ -18,11 +18,16 @@
 
 namespace kifs {
 
-// ---- quaternion step q <- q^2 + c (quaternions.wgsl:42-50 + :26-28) ---------------
+// ---- quaternion helpers (quaternions.wgsl) ----------------------------------------------
+// Evaluation order of the quaternion step (a legal reading of quaternions.wgsl:22-28,42-50,
+// chosen because it is exactly what the packed-f32 loop below computes):
+//     s = y*y + z*z;  d = fma(w,w,s) = |ijk|^2;  |q|^2 = fma(x,x,d)
+//     q^2 + c: real = fma(x,x,-d) + c.x;  ijk = fma(2x, ijk, c.ijk)
+KIFS_DEV float quat_ijk2(V4 q) { return fmaf_(q.w, q.w, q.y * q.y + q.z * q.z); }
+KIFS_DEV float quat_norm2(V4 q) { return fmaf_(q.x, q.x, quat_ijk2(q)); }
 KIFS_DEV V4 quat_sq_add(V4 q, V4 c) {
-    float d = dot(V3{q.y, q.z, q.w}, V3{q.y, q.z, q.w});
     float tr = 2.0f * q.x;
-    return V4{fmaf_(q.x, q.x, -d) + c.x, fmaf_(tr, q.y, c.y), fmaf_(tr, q.z, c.z),
+    return V4{fmaf_(q.x, q.x, -quat_ijk2(q)) + c.x, fmaf_(tr, q.y, c.y), fmaf_(tr, q.z, c.z),
               fmaf_(tr, q.w, c.w)};
 }
 
@@ -38,18 +43,79 @@ KIFS_DEV V4 quat_pow(V4 q, float x) {
 }
 
 // ---- Julia ---------------------------------------------------------------------
+// The orbit loop of julia.wgsl:15-23,
+//     dqs *= 4*qs;  q = q^2 + c;  qs = |q|^2;  if (qs > max_distance) break;
+// hand-written for gfx950.  A frame's run time is the latency of its longest rays, and a
+// lone wave pays ~5 cycles per instruction of any kind, so the loop is written to the
+// minimum instruction count: 8 packed-f32 ops + 1 compare + 1 exec update per trip.
+//
+// Register pairs (fixed, so that 32-bit halves can be named):
+//   v[40:41] YZ = [y, z]          v[42:43] WD = [w, dq]        v[44:45] Q = [|q|^2, x_next]
+//   v[46:47] T  = [2x, 4|q_prev|^2]                            v[48:51] temporaries
+// Per trip (HEAD then TAIL):
+//   YZ = fma(T.lo, YZ, [cy,cz])              y,z of q_{k+1}
+//   WD = fma(T, WD, [cw, 0])                 w of q_{k+1};  dq *= 4|q_{k-1}|^2  (one trip late)
+//   T  = [Q.hi, Q.lo] * [2, 4]               2 x_{k+1}, 4|q_k|^2
+//   A  = YZ*YZ; B = A.lo + A.hi (both lanes); A = fma(WD.lo, WD.lo, B) = d (both lanes)
+//   Q  = fma(Q.hi, Q.hi, [d, -d]) + [0, cx]  = [|q_{k+1}|^2, x_{k+2}]
+//   vcc = |q_{k+1}|^2 > max_distance;  exec &= ~vcc     (an escaped lane's registers freeze)
+// x_{k+2} is computed one trip early from the squares that |q_{k+1}|^2 needs anyway.  The
+// factor 4|q_k|^2 still missing from dq when a lane stops sits frozen in T.hi and is applied
+// after the loop, so dq goes through exactly the products of the textbook loop, in order.
+// The trip count is wave-uniform (SGPR); the loop is unrolled twice with one peeled trip
+// for odd counts and leaves as soon as every lane has escaped.
+#define KIFS_ORBIT_HEAD                                                                    \
+    "v_pk_fma_f32 v[40:41], v[46:47], v[40:41], %[cyz] op_sel_hi:[0,1,1]\n"                  \
+    "v_pk_fma_f32 v[42:43], v[46:47], v[42:43], %[cw0]\n"                                    \
+    "v_pk_mul_f32 v[46:47], v[44:45], %[k24] op_sel:[1,0] op_sel_hi:[0,1]\n"
+#define KIFS_ORBIT_TAIL                                                                    \
+    "v_pk_mul_f32 v[48:49], v[40:41], v[40:41]\n"                                            \
+    "v_pk_add_f32 v[50:51], v[48:49], v[48:49] op_sel:[0,1] op_sel_hi:[0,1]\n"               \
+    "v_pk_fma_f32 v[48:49], v[42:43], v[42:43], v[50:51] op_sel_hi:[0,0,1]\n"                \
+    "v_pk_fma_f32 v[44:45], v[44:45], v[44:45], v[48:49] op_sel:[1,1,0] op_sel_hi:[1,1,1] neg_hi:[0,0,1]\n" \
+    "v_pk_add_f32 v[44:45], v[44:45], %[c0x]\n"
+#define KIFS_ORBIT_TRIP                                                                    \
+    KIFS_ORBIT_HEAD KIFS_ORBIT_TAIL                                                          \
+    "v_cmp_lt_f32 vcc, %[maxd], v44\n"                                                       \
+    "s_andn2_b64 exec, exec, vcc\n"
+
 KIFS_DEV float julia_sdf(const FrameParams& P, V3 p) {
-    float norm = length(p);
-    if (norm > 2.0f + P.epsilon) return norm - 2.0f;  // bounding-sphere patch
-    V4 q{p.x, p.y, p.z, 0.1f};
-    float qs = dot(q, q);
-    float dqs = 1.0f;
-    for (int i = 0; i < P.sdf_iters; ++i) {
-        dqs = dqs * (4.0f * qs);
-        q = quat_sq_add(q, P.c);
-        qs = dot(q, q);
-        if (qs > P.max_distance) break;
-    }
+    const float n2 = dot(p, p);
+    if (n2 > P.bound_n2) return sqrt_(n2) - 2.0f;  // == length(p) > 2 + epsilon (:7-10)
+
+    F2 yz{p.y, p.z};
+    F2 wd{0.1f, 1.0f};          // w = 0.1 (:1), dq = 1 (:14)
+    F2 q{0.0f, p.x};            // .hi = real part of q_0
+    F2 t{p.x + p.x, 1.0f};      // 2 x_0, neutral first dq factor
+    F2 ta, tb;
+    const F2 cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x}, k24{2.0f, 4.0f};
+    int n = P.sdf_iters;
+    unsigned long long saved_exec;
+    asm volatile(
+        KIFS_ORBIT_TAIL  // squares of q_0: Q = [|q_0|^2, x_1]
+        "s_mov_b64 %[save], exec\n"
+        "s_bitcmp1_b32 %[n], 0\n"
+        "s_cbranch_scc0 0f\n"
+        KIFS_ORBIT_TRIP  // odd count: one peeled trip
+        "0:\n"
+        "s_lshr_b32 %[n], %[n], 1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 2f\n"
+        "1:\n"
+        KIFS_ORBIT_TRIP
+        KIFS_ORBIT_TRIP
+        "s_cbranch_execz 2f\n"
+        "s_sub_u32 %[n], %[n], 1\n"
+        "s_cmp_lg_u32 %[n], 0\n"
+        "s_cbranch_scc1 1b\n"
+        "2:\n"
+        "s_mov_b64 exec, %[save]\n"
+        : "+{v[40:41]}"(yz), "+{v[42:43]}"(wd), "+{v[44:45]}"(q), "+{v[46:47]}"(t),
+          "=&{v[48:49]}"(ta), "=&{v[50:51]}"(tb), [save] "=&s"(saved_exec), [n] "+s"(n)
+        : [cyz] "s"(cyz), [cw0] "s"(cw0), [c0x] "s"(c0x), [k24] "s"(k24), [maxd] "s"(P.max_distance)
+        : "vcc", "scc");
+    const float qs = q.x;
+    const float dqs = wd.y * t.y;  // the factor the loop had not applied yet
     return (0.25f * log_(qs)) * sqrt_(qs / dqs);
 }
 
@@ -69,7 +135,7 @@ KIFS_DEV V3 julia_normal(const FrameParams& P, V3 p) {
     for (int i = 0; i < P.normal_iters; ++i) {
         j0 = apply(j0); j1 = apply(j1); j2 = apply(j2); j3 = apply(j3);
         q = quat_sq_add(q, P.c);
-        if (dot(q, q) > P.max_distance) break;
+        if (quat_norm2(q) > P.max_distance) break;
     }
     V3 g;
     g.x = fmaf_(j3.x, q.w, fmaf_(j2.x, q.z, fmaf_(j1.x, q.y, j0.x * q.x)));
@@ -80,10 +146,10 @@ KIFS_DEV V3 julia_normal(const FrameParams& P, V3 p) {
 
 // ---- generalised Julia -----------------------------------------------------------
 KIFS_DEV float genjulia_sdf(const FrameParams& P, V3 p) {
-    float norm = length(p);
-    if (norm > 2.0f + P.epsilon) return norm - 2.0f;
+    const float n2 = dot(p, p);
+    if (n2 > P.bound_n2) return sqrt_(n2) - 2.0f;  // == length(p) > 2 + epsilon
     V4 q{p.x, p.y, p.z, 0.1f};
-    float qs = dot(q, q);
+    float qs = quat_norm2(q);
     float dqs = 1.0f;
     const float pp = P.power * P.power;
     const float pm1 = P.power - 1.0f;
@@ -91,7 +157,7 @@ KIFS_DEV float genjulia_sdf(const FrameParams& P, V3 p) {
         dqs = dqs * (pp * pow_(qs, pm1));
         V4 t = quat_pow(q, P.power);
         q = V4{t.x + P.c.x, t.y + P.c.y, t.z + P.c.z, t.w + P.c.w};
-        qs = dot(q, q);
+        qs = quat_norm2(q);
         if (qs > P.max_distance) break;
     }
     return (0.25f * log_(qs)) * sqrt_(qs / dqs);
@@ -262,30 +328,34 @@ template <int GROUP, int PRIM>
 KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
     float t = 0.0f;
     V3 p = P.origin;
-    int i = 0;
     bool hit = false;
-    bool marching = valid && (i < P.max_iterations) && (t < P.max_distance);
-    int trips = 0;  // wave-uniform count of loop trips
+    // Every marching lane has made the same number of steps, so the loop counter `i` of
+    // entry.wgsl:11 is the wave-uniform trip count (an SGPR); a lane records it when it stops.
+    int trips = 0;
+    int i_final = 0;
+    bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
     while (__ballot(marching) != 0ull) {
         // Long-marching waves are the frame's critical path: raise their issue priority as
         // they age so that co-resident short waves never delay them.
         if (trips == 24) __builtin_amdgcn_s_setprio(1);
         else if (trips == 64) __builtin_amdgcn_s_setprio(2);
         else if (trips == 128) __builtin_amdgcn_s_setprio(3);
-        ++trips;
+        const bool more = (trips + 1) < P.max_iterations;  // scalar
         if (marching) {
             float d = scene_sdf<GROUP, PRIM>(P, p);
             if (d < P.epsilon) {
-                hit = true;
+                hit = true;          // break leaves i un-incremented (:20)
                 marching = false;
+                i_final = trips;
             } else {
                 t = t + d;
                 p = V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
                        fmaf_(t, dir.z, P.origin.z)};
-                ++i;
-                marching = (i < P.max_iterations) && (t < P.max_distance);
+                marching = more && (t < P.max_distance);
+                i_final = trips + 1;
             }
         }
+        ++trips;
     }
     __builtin_amdgcn_s_setprio(0);
     V3 colour = P.background_color;
@@ -297,7 +367,7 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
                     diffuse * P.fractal_color.z};
     }
     if (P.is_heatmap) {
-        float f = float(i) / float(P.max_iterations);
+        float f = float(i_final) / float(P.max_iterations);
         colour = V3{f * P.fractal_color.x, f * P.fractal_color.y, f * P.fractal_color.z};
     }
     return colour;

@@ -18,6 +18,7 @@
  *   length(v)     = sqrt(dot(v,v));   normalize(v) = v / length(v)  (IEEE divides)
  *   min(a,b)      = b < a ? b : a;    max(a,b) = a < b ? b : a;   clamp = min(max(e,lo),hi)
  *   a*b + c written in one WGSL expression inside a hot loop is fused where fma_() appears
+ *   quat_sq_norm2(q) = fma(x,x, fma(w,w, y*y + z*z))   (see quat_norm2)
  *   M * v         = fma chain over the columns, column 0 first
  *   structurally-zero products of sparse constant matrices/vectors are dropped
  */
@@ -95,19 +96,27 @@ static void scene_init(Scene* s, const KorScreen* sc, const KorCamera* cam, cons
 
 /* ======================= quaternions (quaternions.wgsl) ===================== */
 
-/* quat_sq, quaternions.wgsl:42-50: (r*r - dot(ijk,ijk), 2*r*ijk) */
+/* The quaternion step is where a long ray spends its time, so its evaluation order is
+ * fixed to what maps 1:1 onto packed-f32 (v_pk_*) instructions on gfx950; all of it is a
+ * legal evaluation of quaternions.wgsl:22-28,42-50:
+ *     s   = y*y + z*z              (two rounded products, one rounded sum)
+ *     d   = fma(w, w, s)           = dot(ijk, ijk)
+ *     |q|^2 = fma(x, x, d)         quat_sq_norm2
+ *     q^2 + c: real = fma(x, x, -d) + c.x ;  ijk = fma(2x, ijk, c.ijk)               */
+static inline float quat_ijk2(v4 q) { return fma_(q.w, q.w, q.y * q.y + q.z * q.z); }
+
+static inline float quat_norm2(v4 q) { return fma_(q.x, q.x, quat_ijk2(q)); }
+
+/* quat_sq, quaternions.wgsl:42-50 */
 static inline v4 quat_sq(v4 q) {
-    float d = dot3((v3){q.y, q.z, q.w}, (v3){q.y, q.z, q.w});
     float tr = 2.0f * q.x;
-    return (v4){fma_(q.x, q.x, -d), tr * q.y, tr * q.z, tr * q.w};
+    return (v4){fma_(q.x, q.x, -quat_ijk2(q)), tr * q.y, tr * q.z, tr * q.w};
 }
 
-/* quat_add(quat_sq(q), c) as one step, julia.wgsl:17 / :47.  The i,j,k lanes
- * fuse the product 2r*ijk with the addition of c. */
+/* quat_add(quat_sq(q), c) as one step, julia.wgsl:17 / :47 */
 static inline v4 quat_sq_add(v4 q, v4 c) {
-    float d = dot3((v3){q.y, q.z, q.w}, (v3){q.y, q.z, q.w});
     float tr = 2.0f * q.x;
-    return (v4){fma_(q.x, q.x, -d) + c.x, fma_(tr, q.y, c.y), fma_(tr, q.z, c.z),
+    return (v4){fma_(q.x, q.x, -quat_ijk2(q)) + c.x, fma_(tr, q.y, c.y), fma_(tr, q.z, c.z),
                 fma_(tr, q.w, c.w)};
 }
 
@@ -139,13 +148,13 @@ static float julia_sdf(Scene* s, v3 p) {
     if (norm > 2.0f + s->epsilon) return norm - 2.0f; /* :8-10 */
 
     v4 q = {p.x, p.y, p.z, 0.1f};               /* :12, w = 0.1 (:1) */
-    float qs = dot4(q, q);                      /* :13 */
+    float qs = quat_norm2(q);                   /* :13 */
     float dqs = 1.0f;                           /* :14 */
     for (int i = 0; i < s->sdf_iters; i++) {    /* :15 */
         s->n_inner++;
         dqs = dqs * (4.0f * qs);                /* :16 */
         q = quat_sq_add(q, s->c);               /* :17 */
-        qs = dot4(q, q);                        /* :19 */
+        qs = quat_norm2(q);                     /* :19 */
         if (qs > s->max_distance) break;        /* :20-22 */
     }
     return (0.25f * kor_logf(qs)) * sqrtf(qs / dqs); /* :26 */
@@ -168,7 +177,7 @@ static v3 julia_normal(Scene* s, v3 p) {
             J[j] = r;
         }
         q = quat_sq_add(q, s->c);               /* :47-48 */
-        if (dot4(q, q) > s->max_distance) break; /* :50-52 */
+        if (quat_norm2(q) > s->max_distance) break; /* :50-52 */
     }
     /* (J * q_vec).xyz, :55 */
     v3 g;
@@ -185,7 +194,7 @@ static float genjulia_sdf(Scene* s, v3 p) {
     float norm = len3(p);
     if (norm > 2.0f + s->epsilon) return norm - 2.0f; /* gen_julia.wgsl:7-10 */
     v4 q = {p.x, p.y, p.z, 0.1f};
-    float qs = dot4(q, q);
+    float qs = quat_norm2(q);
     float dqs = 1.0f;
     float pp = s->power * s->power;
     float pm1 = s->power - 1.0f;
@@ -194,7 +203,7 @@ static float genjulia_sdf(Scene* s, v3 p) {
         dqs = dqs * (pp * kor_powf(qs, pm1));   /* :16 */
         v4 t = quat_pow(q, s->power);           /* :17 */
         q = (v4){t.x + s->c.x, t.y + s->c.y, t.z + s->c.z, t.w + s->c.w};
-        qs = dot4(q, q);
+        qs = quat_norm2(q);
         if (qs > s->max_distance) break;
     }
     return (0.25f * kor_logf(qs)) * sqrtf(qs / dqs); /* :26 */
