@@ -79,44 +79,78 @@ KIFS_DEV V4 quat_pow(V4 q, float x) {
     "v_cmp_lt_f32 vcc, %[maxd], v44\n"                                                       \
     "s_andn2_b64 exec, exec, vcc\n"
 
-KIFS_DEV float julia_sdf(const FrameParams& P, V3 p) {
-    const float n2 = dot(p, p);
-    if (n2 > P.bound_n2) return sqrt_(n2) - 2.0f;  // == length(p) > 2 + epsilon (:7-10)
-
+// Orbit + distance estimate for points inside the bounding sphere.  `lanes` is the exec mask
+// of the lanes whose result is wanted (wave-uniform SGPR pair); the others keep garbage.
+// The trip count is wave-uniform: the loop is unrolled six times (a taken branch costs a lone
+// wave ~35 cycles, as much as half a trip) with a one-trip remainder loop in front, and leaves
+// as soon as every lane has escaped.
+KIFS_DEV float julia_interior(const FrameParams& P, V3 p, unsigned long long lanes) {
     F2 yz{p.y, p.z};
-    F2 wd{0.1f, 1.0f};          // w = 0.1 (:1), dq = 1 (:14)
-    F2 q{0.0f, p.x};            // .hi = real part of q_0
+    F2 wd{0.1f, 1.0f};          // w = 0.1 (julia.wgsl:1), dq = 1 (:14)
+    F2 q{1.0f, p.x};            // .hi = real part of q_0 (.lo is overwritten by the first TAIL)
     F2 t{p.x + p.x, 1.0f};      // 2 x_0, neutral first dq factor
     F2 ta, tb;
     const F2 cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x}, k24{2.0f, 4.0f};
-    int n = P.sdf_iters;
+    int n = P.sdf_iters, rem;
     unsigned long long saved_exec;
     asm volatile(
-        KIFS_ORBIT_TAIL  // squares of q_0: Q = [|q_0|^2, x_1]
         "s_mov_b64 %[save], exec\n"
-        "s_bitcmp1_b32 %[n], 0\n"
-        "s_cbranch_scc0 0f\n"
-        KIFS_ORBIT_TRIP  // odd count: one peeled trip
+        "s_and_b64 exec, exec, %[lanes]\n"
+        KIFS_ORBIT_TAIL  // squares of q_0: Q = [|q_0|^2, x_1]
+        // rem = n % 6 single trips, then n / 6 blocks of six
+        "s_mul_hi_u32 %[rem], %[n], 0x2aaaaaab\n"   // n / 6 for 0 <= n < 2^31
+        "s_mul_i32 %[rem], %[rem], 6\n"
+        "s_sub_u32 %[rem], %[n], %[rem]\n"
+        "s_sub_u32 %[n], %[n], %[rem]\n"
+        "s_cmp_eq_u32 %[rem], 0\n"
+        "s_cbranch_scc1 1f\n"
         "0:\n"
-        "s_lshr_b32 %[n], %[n], 1\n"
-        "s_cmp_eq_u32 %[n], 0\n"
-        "s_cbranch_scc1 2f\n"
+        KIFS_ORBIT_TRIP
+        "s_sub_u32 %[rem], %[rem], 1\n"
+        "s_cmp_lg_u32 %[rem], 0\n"
+        "s_cbranch_scc1 0b\n"
         "1:\n"
-        KIFS_ORBIT_TRIP
-        KIFS_ORBIT_TRIP
-        "s_cbranch_execz 2f\n"
-        "s_sub_u32 %[n], %[n], 1\n"
-        "s_cmp_lg_u32 %[n], 0\n"
-        "s_cbranch_scc1 1b\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 3f\n"
         "2:\n"
+        KIFS_ORBIT_TRIP KIFS_ORBIT_TRIP KIFS_ORBIT_TRIP
+        "s_cbranch_execz 3f\n"
+        KIFS_ORBIT_TRIP KIFS_ORBIT_TRIP KIFS_ORBIT_TRIP
+        "s_cbranch_execz 3f\n"
+        "s_sub_u32 %[n], %[n], 6\n"
+        "s_cmp_lg_u32 %[n], 0\n"
+        "s_cbranch_scc1 2b\n"
+        "3:\n"
         "s_mov_b64 exec, %[save]\n"
         : "+{v[40:41]}"(yz), "+{v[42:43]}"(wd), "+{v[44:45]}"(q), "+{v[46:47]}"(t),
-          "=&{v[48:49]}"(ta), "=&{v[50:51]}"(tb), [save] "=&s"(saved_exec), [n] "+s"(n)
-        : [cyz] "s"(cyz), [cw0] "s"(cw0), [c0x] "s"(c0x), [k24] "s"(k24), [maxd] "s"(P.max_distance)
+          "=&{v[48:49]}"(ta), "=&{v[50:51]}"(tb), [save] "=&s"(saved_exec), [n] "+s"(n),
+          [rem] "=&s"(rem)
+        : [cyz] "s"(cyz), [cw0] "s"(cw0), [c0x] "s"(c0x), [k24] "s"(k24),
+          [maxd] "s"(P.max_distance), [lanes] "s"(lanes)
         : "vcc", "scc");
     const float qs = q.x;
     const float dqs = wd.y * t.y;  // the factor the loop had not applied yet
-    return (0.25f * log_(qs)) * sqrt_(qs / dqs);
+    // zero / denormal / inf / NaN |q|^2 is rare: only then does the wave run the general log
+    const bool ordinary = (qs >= 1.17549435e-38f) && (qs <= 3.40282347e38f);
+    float lg;
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(!ordinary) & lanes) == 0ull, 1))
+        lg = log_normal(qs);
+    else
+        lg = log_general(qs);
+    return (0.25f * lg) * sqrt_(qs / dqs);
+}
+
+// scene_SDF of julia.wgsl:5-27 for one point (point evaluation, normals of other variants).
+KIFS_DEV float julia_sdf(const FrameParams& P, V3 p) {
+    const float n2 = dot(p, p);
+    const bool outside = n2 > P.bound_n2;  // == length(p) > 2 + epsilon (:7-10)
+    const unsigned long long in_lanes = __builtin_amdgcn_ballot_w64(!outside);
+    float d = sqrt_(n2) - 2.0f;
+    if (in_lanes != 0ull) {
+        float di = julia_interior(P, p, in_lanes);
+        d = outside ? d : di;
+    }
+    return d;
 }
 
 KIFS_DEV V3 julia_normal(const FrameParams& P, V3 p) {
@@ -319,6 +353,66 @@ KIFS_DEV V3 ray_direction(const FrameParams& P, int x, int y) {
     return normalize(d);
 }
 
+// ---- raymarch for the Julia pipeline: control flow kept wave-uniform ----------------------
+// Same results as the generic loop below.  Each trip classifies the wave with two ballots:
+// every marching lane inside the bounding sphere (the state of all long rays: one straight
+// run through julia_interior), every marching lane outside (background: a sqrt and a
+// subtract), or mixed.  That keeps taken branches -- the expensive thing for a lone wave --
+// to the loop's back edge.
+KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid) {
+    float t = 0.0f;
+    V3 p = P.origin;
+    bool hit = false;
+    int trips = 0;     // == the loop counter i of entry.wgsl:11 for every marching lane
+    int i_final = 0;
+    bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
+    for (;;) {
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(marching);
+        if (live == 0ull) break;
+        if (trips == 32) __builtin_amdgcn_s_setprio(3);  // long rays are the critical path
+        const bool more = (trips + 1) < P.max_iterations;
+        const float n2 = dot(p, p);
+        const bool outside = n2 > P.bound_n2;  // == length(p) > 2 + epsilon
+        const unsigned long long out_lanes = __builtin_amdgcn_ballot_w64(outside) & live;
+        float d;
+        if (__builtin_expect(out_lanes == 0ull, 1)) {
+            d = julia_interior(P, p, live);
+        } else {
+            d = sqrt_(n2) - 2.0f;
+            const unsigned long long in_lanes = live & ~out_lanes;
+            if (in_lanes != 0ull) {
+                float di = julia_interior(P, p, in_lanes);
+                d = outside ? d : di;
+            }
+        }
+        const bool h = marching && (d < P.epsilon);
+        const bool go = marching && !h;
+        hit = hit || h;
+        if (__builtin_expect(P.is_heatmap != 0u, 0))  // i is only observable in heatmap mode
+            i_final = h ? trips : (go ? trips + 1 : i_final);
+        const float tn = t + d;
+        t = go ? tn : t;
+        p = V3{go ? fmaf_(tn, dir.x, P.origin.x) : p.x, go ? fmaf_(tn, dir.y, P.origin.y) : p.y,
+               go ? fmaf_(tn, dir.z, P.origin.z) : p.z};
+        marching = go && more && (tn < P.max_distance);
+        ++trips;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    V3 colour = P.background_color;
+    if (hit) {
+        V3 n = julia_normal(P, p);
+        float ndl = (n.x + n.y) + n.z;
+        float diffuse = fmaf_(0.9f, clamp_(ndl, 0.0f, 1.0f), 0.1f);
+        colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
+                    diffuse * P.fractal_color.z};
+    }
+    if (P.is_heatmap) {
+        float f = float(i_final) / float(P.max_iterations);
+        colour = V3{f * P.fractal_color.x, f * P.fractal_color.y, f * P.fractal_color.z};
+    }
+    return colour;
+}
+
 // ---- raymarch (entry.wgsl:6-29), wave64 form ------------------------------------------
 // Lanes march in lock step; a lane drops out on hit, on i == max_iterations or on
 // t >= max_distance.  The loop leaves as soon as __ballot says no lane is still
@@ -326,6 +420,7 @@ KIFS_DEV V3 ray_direction(const FrameParams& P, int x, int y) {
 // the loop, for the lanes that hit, so that divergent work is bunched together.
 template <int GROUP, int PRIM>
 KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
+    if constexpr (GROUP == GROUP_JULIA) return raymarch_julia(P, dir, valid);
     float t = 0.0f;
     V3 p = P.origin;
     bool hit = false;
@@ -337,9 +432,7 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
     while (__ballot(marching) != 0ull) {
         // Long-marching waves are the frame's critical path: raise their issue priority as
         // they age so that co-resident short waves never delay them.
-        if (trips == 24) __builtin_amdgcn_s_setprio(1);
-        else if (trips == 64) __builtin_amdgcn_s_setprio(2);
-        else if (trips == 128) __builtin_amdgcn_s_setprio(3);
+        if (trips == 32) __builtin_amdgcn_s_setprio(3);
         const bool more = (trips + 1) < P.max_iterations;  // scalar
         if (marching) {
             float d = scene_sdf<GROUP, PRIM>(P, p);
