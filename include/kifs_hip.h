@@ -168,6 +168,20 @@ int kifs_eval_points(kifs_ctx* ctx, const float* points_xyz, int n, float* sdf_o
  * 8 UNORM-encode. */
 int kifs_eval_math(kifs_ctx* ctx, int fn, const float* in, float param, float* out, int n);
 
+/* Diagnostics: with enable != 0, subsequent Julia renders write one record per wave into a
+ * device buffer sized for the current screen; each call zeroes the buffer (out[8] receives
+ * the 8 reserved header words).  enable == 0 frees it.  Not for timed runs. */
+int kifs_debug_counters(kifs_ctx* ctx, int enable, unsigned long long out[8]);
+/* Tuning hooks: read / replace the order in which workgroups take the tiles of the full
+ * frame (a permutation of (tile_x | tile_y << 16)); the order only affects speed. */
+int kifs_debug_get_tile_order(kifs_ctx* ctx, uint32_t* order, size_t max_count, size_t* count);
+int kifs_debug_set_tile_order(kifs_ctx* ctx, const uint32_t* order, size_t count);
+/* Per-wave records of the last counted render: 4 words per wave (wave = 4 * workgroup + wave
+ * in workgroup, workgroups in dispatch order): total s_memtime ticks, ticks in the long-ray
+ * loop, long-ray steps | (entries << 32), general steps.  Copies up to max_waves records. */
+int kifs_debug_wave_records(kifs_ctx* ctx, unsigned long long* out, size_t max_waves,
+                            size_t* n_waves);
+
 /* ---- host model: the reference's scene -> uniform packing --------------------
  * C++ restatement of the caller side of the boundary so a harness without the
  * Rust host produces the same 156 bytes.

@@ -55,6 +55,8 @@ struct kifs_ctx {
     int sdf_iters = 100, normal_iters = 10, fold_iters = 10;  // julia.wgsl:2-3, kifs.wgsl:72
     double last_ms = -1.0;
     bool timing_pending = false;
+    unsigned long long* d_counters = nullptr;  // diagnostics buffer, see FrameParams
+    size_t counter_words = 0;
 };
 
 namespace {
@@ -131,6 +133,8 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->normal_iters = c->normal_iters;
     P->fold_iters = c->fold_iters;
     P->bound_n2 = squared_threshold(2.0f + o.epsilon);
+    P->orbit_blocks = c->sdf_iters / 6;
+    P->orbit_rem = c->sdf_iters % 6;
     P->width = w;
     P->y0 = 0;
     P->y1 = h;
@@ -140,6 +144,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->srgb_table = c->d_srgb;
     P->tile_order = nullptr;
     P->tile_count = 0;
+    P->counters = c->d_counters;
     return KIFS_OK;
 }
 
@@ -290,6 +295,7 @@ void kifs_destroy(kifs_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& t : c->tables)
         if (t.d_order) (void)hipFree(t.d_order);
+    if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_srgb) (void)hipFree(c->d_srgb);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -399,6 +405,89 @@ int kifs_synchronize(kifs_ctx* c) {
     if (!c) return KIFS_ERR_BAD_ARG;
     DeviceGuard g(c->device);
     return hipStreamSynchronize(c->stream) == hipSuccess ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+// Diagnostics buffer: 8 aggregate counters followed by one 4-word record per wave of the
+// largest frame the context can be asked for with the current screen (4 waves per tile).
+static size_t debug_words(const kifs_ctx* c) {
+    int w = 0, h = 0;
+    if (!c->have_screen || frame_dims(c, &w, &h) != KIFS_OK) return 8;
+    size_t tiles = size_t((w + kifs::TILE_W - 1) / kifs::TILE_W) * size_t((h + kifs::TILE_H - 1) / kifs::TILE_H);
+    return 8 + 16 * tiles;
+}
+
+int kifs_debug_counters(kifs_ctx* c, int enable, unsigned long long out[8]) {
+    if (!c) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+    if (c->d_counters && out &&
+        hipMemcpy(out, c->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return KIFS_ERR_RUNTIME;
+    const size_t words = debug_words(c);
+    if (enable && (!c->d_counters || c->counter_words != words)) {
+        if (c->d_counters) (void)hipFree(c->d_counters);
+        c->d_counters = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_counters), words * sizeof(unsigned long long)) != hipSuccess)
+            return KIFS_ERR_RUNTIME;
+        c->counter_words = words;
+    }
+    if (c->d_counters &&
+        hipMemset(c->d_counters, 0, c->counter_words * sizeof(unsigned long long)) != hipSuccess)
+        return KIFS_ERR_RUNTIME;
+    if (!enable && c->d_counters) {
+        (void)hipFree(c->d_counters);
+        c->d_counters = nullptr;
+        c->counter_words = 0;
+    }
+    return KIFS_OK;
+}
+
+int kifs_debug_set_tile_order(kifs_ctx* c, const uint32_t* order, size_t count) {
+    if (!c || !order) return KIFS_ERR_BAD_ARG;
+    int w, h;
+    if (!c->have_screen || frame_dims(c, &w, &h) != KIFS_OK) return KIFS_ERR_UNCONFIGURED;
+    DeviceGuard g(c->device);
+    const TileTable* tt = tile_table(c, w, h, 0, h);
+    if (!tt) return KIFS_ERR_RUNTIME;
+    if (count != tt->count) return KIFS_ERR_BAD_ARG;
+    std::vector<char> seen(count, 0);  // must be a permutation of the frame's tiles
+    const uint32_t tx = uint32_t((w + kifs::TILE_W - 1) / kifs::TILE_W);
+    const uint32_t ty = uint32_t((h + kifs::TILE_H - 1) / kifs::TILE_H);
+    for (size_t i = 0; i < count; ++i) {
+        uint32_t x = order[i] & 0xffffu, y = order[i] >> 16;
+        if (x >= tx || y >= ty || seen[size_t(y) * tx + x]) return KIFS_ERR_BAD_ARG;
+        seen[size_t(y) * tx + x] = 1;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return KIFS_ERR_RUNTIME;
+    return hipMemcpy(tt->d_order, order, count * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess
+               ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+int kifs_debug_get_tile_order(kifs_ctx* c, uint32_t* order, size_t max_count, size_t* count) {
+    if (!c || !order || !count) return KIFS_ERR_BAD_ARG;
+    int w, h;
+    if (!c->have_screen || frame_dims(c, &w, &h) != KIFS_OK) return KIFS_ERR_UNCONFIGURED;
+    DeviceGuard g(c->device);
+    const TileTable* tt = tile_table(c, w, h, 0, h);
+    if (!tt) return KIFS_ERR_RUNTIME;
+    if (tt->count > max_count) return KIFS_ERR_BAD_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return KIFS_ERR_RUNTIME;
+    *count = tt->count;
+    return hipMemcpy(order, tt->d_order, tt->count * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess
+               ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+int kifs_debug_wave_records(kifs_ctx* c, unsigned long long* out, size_t max_waves, size_t* n_waves) {
+    if (!c || !out || !n_waves) return KIFS_ERR_BAD_ARG;
+    if (!c->d_counters) return KIFS_ERR_UNCONFIGURED;
+    DeviceGuard g(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+    size_t waves = (c->counter_words - 8) / 4;
+    if (waves > max_waves) waves = max_waves;
+    if (hipMemcpy(out, c->d_counters + 8, waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return KIFS_ERR_RUNTIME;
+    *n_waves = waves;
+    return KIFS_OK;
 }
 
 int kifs_eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float* nrm_out) {

@@ -20,6 +20,8 @@
 // Replaces: vs_main + rasteriser + fs_main + ROP of the reference
 // (src/shaders/dependencies/entry.wgsl:35-59, src/render/graphics.rs:310-325,
 // src/render.rs:72-80).
+#include <cstdlib>
+
 #include "kifs_internal.hpp"
 #include "kifs_scene.hpp"
 
@@ -75,12 +77,39 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
         P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
 }
 
+// Dynamic LDS requested only to cap how many workgroups share a CU (the kernel never touches
+// it).  A Julia frame is bound by the latency of its longest rays, and those slow each other
+// down badly once three or more share a SIMD (measured: ~1490 ticks per march step alone,
+// ~1700 at 3 waves/SIMD, ~1900 at 8), while the dispatcher happily co-locates them.  For a
+// frame small enough that the rest of its work hides in the shadow of those rays, two
+// workgroups per CU is the best trade (1080p: 213 -> 183 us); a large frame is throughput
+// bound and keeps full residency (4096^2: 0.71 ms vs 1.31 ms capped).
+// KIFS_LDS_PAD=<bytes> overrides the rule (tuning).
+constexpr unsigned TWO_PER_CU_PAD = 72 * 1024;    // 2 KiB static + 72 KiB: two fit in 160 KiB, three do not
+constexpr unsigned SMALL_FRAME_TILES = 16384;     // 32x8-pixel tiles: about 4.2 Mpixel
+
+static unsigned residency_pad_bytes(int group, unsigned tile_count) {
+    static const long forced = [] {
+        const char* e = std::getenv("KIFS_LDS_PAD");
+        return e ? std::strtol(e, nullptr, 10) : -1L;
+    }();
+    if (forced >= 0) return unsigned(forced);
+    return (group == GROUP_JULIA && tile_count <= SMALL_FRAME_TILES) ? TWO_PER_CU_PAD : 0u;
+}
+
 // Pipeline selection: the reference keeps three render pipelines and picks one per
 // frame by fractal_group (graphics.rs:310-321); the KIFS shader then switches on
 // primitive_id per SDF call (kifs.wgsl:139-155).  Here both are template parameters.
 template <int GROUP, int PRIM>
 static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
-    hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), dim3(P.tile_count), dim3(BLOCK), 0, stream, P);
+    const unsigned pad = residency_pad_bytes(GROUP, P.tile_count);
+    if (pad > 48 * 1024) {  // beyond the default dynamic-LDS limit: opt in once per kernel
+        static const hipError_t attr = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&render_kernel<GROUP, PRIM>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), dim3(P.tile_count), dim3(BLOCK), pad, stream, P);
     return hipGetLastError();
 }
 

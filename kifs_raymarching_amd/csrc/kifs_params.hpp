@@ -29,6 +29,7 @@ struct FrameParams {
     // Largest f32 v with sqrt(v) <= 2 + epsilon: `length(p) > 2 + epsilon` (julia.wgsl:8) is
     // exactly `dot(p,p) > bound_n2` because correctly rounded sqrt is monotone.
     float bound_n2;
+    int orbit_blocks, orbit_rem;        // sdf_iters = 6 * orbit_blocks + orbit_rem
     int width, y0, y1;                  // frame width, row band [y0, y1)
     int encode;                         // KifsEncode
     uint32_t pitch_words;               // output row pitch in 32-bit words
@@ -36,6 +37,10 @@ struct FrameParams {
     const float* srgb_table;            // 256 thresholds, device memory
     const uint32_t* tile_order;         // workgroup b renders tile (order[b] & 0xffff, order[b] >> 16)
     uint32_t tile_count;
+    // Optional device counters (nullptr in normal operation): [0] wave-steps taken in the
+    // hand-written long-ray loop, [1] wave-steps taken on the general path, [2] entries into
+    // the long-ray loop, [3] waves.  Enabled by kifs_debug_counters().
+    unsigned long long* counters;
 };
 
 }  // namespace kifs

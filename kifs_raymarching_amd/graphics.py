@@ -296,6 +296,41 @@ class GraphicState:
         check(lib.kifs_eval_points(self._ctx, fp(pts), n, fp(sdf), fp(nrm)), "eval_points")
         return sdf, nrm
 
+    def debug_counters(self, enable: bool = True):
+        """Switch per-wave diagnostics on/off (and reset them); returns the sums of the records
+        written since the last call (see kifs_debug_wave_records)."""
+        try:
+            rec = self.debug_wave_records()
+        except KifsError:
+            rec = np.zeros((0, 4), dtype=np.uint64)
+        out = (C.c_uint64 * 8)()
+        check(lib.kifs_debug_counters(self._ctx, 1 if enable else 0, out), "debug_counters")
+        rec = rec[rec[:, 0] > 0]
+        return dict(fast_steps=int((rec[:, 2] & np.uint64(0xffffffff)).sum()),
+                    fast_entries=int((rec[:, 2] >> np.uint64(32)).sum()),
+                    general_steps=int(rec[:, 3].sum()), waves=len(rec),
+                    fast_ticks=int(rec[:, 1].sum()), wave_ticks=int(rec[:, 0].sum()))
+
+    def debug_get_tile_order(self):
+        buf = np.zeros(1 << 22, dtype=np.uint32)
+        n = C.c_size_t(0)
+        check(lib.kifs_debug_get_tile_order(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            buf.size, C.byref(n)), "get_tile_order")
+        return buf[:n.value].copy()
+
+    def debug_set_tile_order(self, order):
+        o = np.ascontiguousarray(order, dtype=np.uint32)
+        check(lib.kifs_debug_set_tile_order(self._ctx, o.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            o.size), "set_tile_order")
+
+    def debug_wave_records(self, max_waves: int = 1 << 20):
+        """(n_waves, 4) uint64: total ticks, long-ray-loop ticks, long-ray steps, general steps."""
+        buf = np.zeros((max_waves, 4), dtype=np.uint64)
+        n = C.c_size_t(0)
+        check(lib.kifs_debug_wave_records(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          max_waves, C.byref(n)), "debug_wave_records")
+        return buf[:n.value]
+
     def eval_math(self, fn: int, x, param: float = 0.0):
         xs = np.ascontiguousarray(x, dtype=np.float32).ravel()
         out = np.empty_like(xs)
