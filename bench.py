@@ -3,11 +3,16 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A "step" is one frame of the workload: one launch of the HIP render kernel over the
-frame (N = 1) or over this rank's row band followed by the RCCL gather of the bands into
-rank 0's frame (N > 1, one process per GPU, launched by torch.distributed.run).  The
-default workload is BASELINE.json's metric configuration: 1920x1080 quaternion-Julia,
-256 march steps, 12 SDF iterations.  Rank 0 prints ONE JSON line.
+A "step" is one frame of the workload per rank: one launch of the HIP render kernel over
+the frame.  At N > 1 (one process per GPU, launched by torch.distributed.run) the default
+is frame-parallel: in each step every rank renders one whole frame of the sequence and the
+finished frames are delivered to rank 0 by grouped RCCL point-to-point transfers over xGMI
+(weak scaling: per-GPU work is fixed, value = N x pixels per step / time).  `--shard bands`
+instead splits every frame into row bands gathered into rank 0's frame (strong scaling of
+one frame: the low-latency mode; it cannot raise throughput much because every band still
+contains the frame's longest rays -- DESIGN.md section 6).  The default workload is
+BASELINE.json's metric configuration: 1920x1080 quaternion-Julia, 256 march steps, 12 SDF
+iterations.  Rank 0 prints ONE JSON line.
 
 There are no HBM-resident inputs beyond the 156 uniform bytes; the output frame lives in
 HBM (torch tensor) and is written by the kernel.  `roofline` prices the dominant kernel
@@ -39,6 +44,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall-clock budget of the cpu_baseline sample (0 disables it)")
     ap.add_argument("--encode", type=int, default=1, help="1 = sRGB target (reference default), 0 = UNORM")
+    ap.add_argument("--shard", default="frames", choices=["frames", "bands"],
+                    help="N > 1: whole frames per rank (throughput, default) or row bands of each frame (latency)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo is only for rehearsing N > 1 on one GPU")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region, compare rank 0's gathered frame with a single-GPU render")
     return ap.parse_args()
 
 
@@ -96,7 +109,7 @@ def main():
     import torch.distributed as dist
 
     import kifs_raymarching_amd as K
-    from kifs_raymarching_amd.bands import BandFrame
+    from kifs_raymarching_amd.bands import BandFrame, FrameStream
     from kifs_raymarching_amd.configs import HEADLINE, WORKLOADS
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,10 +122,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the render path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     key = args.workload or HEADLINE
     w = WORKLOADS[key]
@@ -123,14 +141,26 @@ def main():
     # one dedicated non-default stream, made current for the whole benchmark.
     stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(stream)
-    bf = BandFrame(W, H, rank, world, device)
+    frames_mode = world > 1 and args.shard == "frames"
+    if frames_mode:
+        bf = FrameStream(W, H, rank, world, device)
+        rows0 = H
 
-    def render_band(out, y0, y1):
-        gs.render_async(out, stream=stream, y0=y0, y1=y1, encode=args.encode)
+        def render_band(out, frame_index):  # every frame of the synthetic sequence is the same view
+            gs.render_async(out, stream=stream, y0=0, y1=H, encode=args.encode)
+    else:
+        bf = BandFrame(W, H, rank, world, device)
+        rows0 = bf.y1 - bf.y0
+
+        def render_band(out, y0, y1):
+            gs.render_async(out, stream=stream, y0=y0, y1=y1, encode=args.encode)
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     for k in range(args.warmup):
         bf.step(k, render_band)
@@ -153,19 +183,30 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        red_dev = device if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tk = torch.tensor([dev_ms], dtype=torch.float64, device=device)
+        tk = torch.tensor([dev_ms], dtype=torch.float64, device=red_dev)
         gathered = [torch.zeros_like(tk) for _ in range(world)]
         dist.all_gather(gathered, tk)
         per_rank_ms = [float(x.item()) / args.steps for x in gathered]
     else:
         per_rank_ms = [dev_ms / args.steps]
 
+    check = None
+    if args.check and rank == 0:
+        last = (args.steps - 1) if args.steps > 0 else (args.warmup - 1)
+        ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
+        gs.render(out=ref, encode=args.encode)
+        if frames_mode:
+            check = all(bool(torch.equal(f, ref)) for f in bf.frames(last))
+        else:
+            check = bool(torch.equal(bf.frame(last), ref))
+
     if rank == 0:
-        mpix = W * H * args.steps / elapsed / 1e6
-        rows0 = bf.y1 - bf.y0
+        frames_per_step = world if frames_mode else 1
+        mpix = frames_per_step * W * H * args.steps / elapsed / 1e6
         launch_s = dev_ms / 1e3 / args.steps
         alg_bytes = 4.0 * W * rows0  # 4 B written per pixel, 0 read
         achieved = alg_bytes / launch_s / 1e9
@@ -178,7 +219,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if (frames_mode or world == 1) else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -187,7 +228,9 @@ def main():
                        "normal_iters": w.iters[1], "fold_iters": w.iters[2],
                        "encode": "srgb8" if args.encode else "unorm8",
                        "parallelism": "1 GPU, one launch per frame" if world == 1 else
-                       f"{world} row bands, one process per GPU, RCCL p2p gather to rank 0"},
+                       (f"{world} GPUs x whole frames (frame-parallel), one process per GPU, "
+                        "finished frames sent to rank 0 by grouped RCCL p2p" if frames_mode else
+                        f"{world} row bands per frame, one process per GPU, RCCL p2p gather to rank 0")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic(key) if world == 1 else None,
@@ -195,6 +238,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
             "per_rank_kernel_ms": [round(x, 5) for x in per_rank_ms],
         }
+        if check is not None:
+            out["gathered_frame_equals_single_gpu_frame"] = check
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         print(json.dumps(out), flush=True)

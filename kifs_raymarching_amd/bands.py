@@ -1,4 +1,13 @@
-"""Row-band sharding of one frame over the ranks of a node, gathered to a root rank.
+"""Multi-GPU sharding of the render path: row bands of one frame (BandFrame) or whole frames
+of a sequence (FrameStream), both delivered to a root rank by grouped point-to-point RCCL.
+
+Which one to use.  A frame's run time is the critical path of its longest rays (hundreds of
+dependent march steps), and every row band of the fractal still contains such rays, so bands
+barely shorten a frame: they are the low-LATENCY option.  THROUGHPUT scales over frames --
+the frames of an orbit are independent -- so FrameStream gives each rank whole frames and
+streams the finished ones to the root; that is the default of bench.py at N > 1.
+
+Row-band sharding of one frame over the ranks of a node, gathered to a root rank.
 
 Pixels are independent (entry.wgsl:49-59 reads only uniforms and its own position), so
 the frame shards by contiguous row bands: rank r renders rows kifs_band_range(H, r, N)
@@ -46,6 +55,16 @@ class BandFrame:
             self._bands = [torch.zeros((rows, width, 4), dtype=torch.uint8, device=self.device)
                            for _ in range(buffers)]
         self._works: List[Optional[list]] = [None] * buffers
+        # gloo cannot move device memory: rehearsals of the N > 1 path on a single GPU (two
+        # ranks sharing cuda:0) stage the bands through host buffers.  RCCL never takes this path.
+        self._staged = (world > 1 and self.device.type == "cuda"
+                        and dist.get_backend(group) == "gloo")
+        if self._staged:
+            if rank == root:
+                self._host = [[torch.empty((b - a, width, 4), dtype=torch.uint8) for a, b in self.ranges]
+                              for _ in range(buffers)]
+            else:
+                self._host = [torch.empty((rows, width, 4), dtype=torch.uint8) for _ in range(buffers)]
 
     # -- buffers ----------------------------------------------------------------------
     def band(self, k: int) -> torch.Tensor:
@@ -64,6 +83,16 @@ class BandFrame:
             return
         slot = k % self.buffers
         ops = []
+        if self._staged:
+            if self.rank == self.root:
+                for r, (a, b) in enumerate(self.ranges):
+                    if r != self.root and b > a:
+                        ops.append(dist.P2POp(dist.irecv, self._host[slot][r], r, self.group))
+            elif self.y1 > self.y0:
+                self._host[slot].copy_(self._bands[slot])  # synchronises with the render stream
+                ops.append(dist.P2POp(dist.isend, self._host[slot], self.root, self.group))
+            self._works[slot] = dist.batch_isend_irecv(ops) if ops else None
+            return
         if self.rank == self.root:
             frame = self._frames[slot]
             for r, (a, b) in enumerate(self.ranges):
@@ -80,6 +109,10 @@ class BandFrame:
         if works:
             for w in works:
                 w.wait()
+            if self._staged and self.rank == self.root:
+                for r, (a, b) in enumerate(self.ranges):
+                    if r != self.root and b > a:
+                        self._frames[slot][a:b].copy_(self._host[slot][r])
         self._works[slot] = None
 
     def wait_all(self):
@@ -93,4 +126,89 @@ class BandFrame:
         self.wait(k)  # gather of frame k - buffers
         if self.y1 > self.y0:
             render_band(self.band(k), self.y0, self.y1)
+        self.gather_async(k)
+
+
+class FrameStream:
+    """Frame-parallel rendering: in step k every rank renders one whole frame (frame index
+    k * world + rank of the sequence) into its own HBM and the root collects all `world`
+    frames of the step: N-1 receives on the root, one send on every other rank, posted as one
+    group so the transfers ride seven different xGMI links at once.  Double-buffered like
+    BandFrame: the transfers of step k overlap the rendering of step k+1."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device,
+                 root: int = 0, buffers: int = 2, group=None):
+        if width <= 0 or height <= 0 or world <= 0 or not (0 <= rank < world):
+            raise ValueError("FrameStream: bad geometry")
+        self.width, self.height = width, height
+        self.rank, self.world, self.root = rank, world, root
+        self.device = torch.device(device)
+        self.group = group
+        self.buffers = buffers
+        shape = (height, width, 4)
+        if rank == root:
+            # slot[b][r] = frame rendered by rank r in a step using buffer b
+            self._slots = [[torch.zeros(shape, dtype=torch.uint8, device=self.device)
+                            for _ in range(world)] for _ in range(buffers)]
+            self._mine = [self._slots[b][root] for b in range(buffers)]
+        else:
+            self._slots = None
+            self._mine = [torch.zeros(shape, dtype=torch.uint8, device=self.device)
+                          for _ in range(buffers)]
+        self._works: List[Optional[list]] = [None] * buffers
+        self._staged = (world > 1 and self.device.type == "cuda"
+                        and dist.get_backend(group) == "gloo")  # rehearsal only, see BandFrame
+        if self._staged:
+            n = world if rank == root else 1
+            self._host = [[torch.empty(shape, dtype=torch.uint8) for _ in range(n)]
+                          for _ in range(buffers)]
+
+    def frame_index(self, k: int) -> int:
+        return k * self.world + self.rank
+
+    def target(self, k: int) -> torch.Tensor:
+        return self._mine[k % self.buffers]
+
+    def frames(self, k: int):
+        """On the root: the `world` frames of step k in sequence order (valid after wait(k))."""
+        return self._slots[k % self.buffers] if self.rank == self.root else None
+
+    def gather_async(self, k: int):
+        if self.world == 1:
+            return
+        slot = k % self.buffers
+        ops = []
+        if self.rank == self.root:
+            for r in range(self.world):
+                if r != self.root:
+                    dst = self._host[slot][r] if self._staged else self._slots[slot][r]
+                    ops.append(dist.P2POp(dist.irecv, dst, r, self.group))
+        else:
+            src = self._mine[slot]
+            if self._staged:
+                self._host[slot][0].copy_(src)
+                src = self._host[slot][0]
+            ops.append(dist.P2POp(dist.isend, src, self.root, self.group))
+        self._works[slot] = dist.batch_isend_irecv(ops)
+
+    def wait(self, k: int):
+        slot = k % self.buffers
+        works = self._works[slot]
+        if works:
+            for w in works:
+                w.wait()
+            if self._staged and self.rank == self.root:
+                for r in range(self.world):
+                    if r != self.root:
+                        self._slots[slot][r].copy_(self._host[slot][r])
+        self._works[slot] = None
+
+    def wait_all(self):
+        for slot in range(self.buffers):
+            self.wait(slot)
+
+    def step(self, k: int, render_frame: Callable[[torch.Tensor, int], None]):
+        """`render_frame(out, frame_index)` renders this rank's frame of step k."""
+        self.wait(k)
+        render_frame(self.target(k), self.frame_index(k))
         self.gather_async(k)

@@ -84,3 +84,53 @@ def test_bandframe_single_rank_needs_no_process_group(kifs):
     assert calls == [((9, 16, 4), 0, 9)] and bf.frame(0).shape == (9, 16, 4)
     with pytest.raises(ValueError):
         BandFrame(0, 9, 0, 1, "cpu")
+
+
+def _frames_worker(rank, world, port, width, height, steps, outdir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from kifs_raymarching_amd.bands import FrameStream
+
+        sc = O.screen_uniform(width, height)
+        opt = O.options_from_gui(primitive_shape=4, max_iterations=40)
+        fs = FrameStream(width, height, rank, world, "cpu")
+
+        def render_frame(out, index):  # frame `index` of an orbit
+            cam = O.camera_uniform(3.0, 0.25 * index, 0.2)
+            out.copy_(torch.from_numpy(O.render(sc, cam, opt, O.iters(100, 10, 6), nthreads=1)))
+
+        got = []
+        for k in range(steps):
+            fs.step(k, render_frame)
+            if k >= 1:
+                fs.wait(k - 1)
+                if rank == 0:
+                    got.extend(f.clone().numpy() for f in fs.frames(k - 1))
+        fs.wait_all()
+        if rank == 0:
+            got.extend(f.clone().numpy() for f in fs.frames(steps - 1))
+            np.save(os.path.join(outdir, "frames.npy"), np.stack(got))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_stream_delivers_the_sequence_in_order(world, tmp_path, oracle):
+    """Frame-parallel mode: step k, rank r renders frame k*world + r; the root ends up with
+    the whole orbit in sequence order, identical to rendering it in one process."""
+    width, height, steps = 40, 30, 3
+    mp.spawn(_frames_worker, args=(world, _free_port(), width, height, steps, str(tmp_path)),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "frames.npy")
+    assert got.shape[0] == steps * world
+    sc = oracle.screen_uniform(width, height)
+    opt = oracle.options_from_gui(primitive_shape=4, max_iterations=40)
+    for i in range(steps * world):
+        want = oracle.render(sc, oracle.camera_uniform(3.0, 0.25 * i, 0.2), opt, oracle.iters(100, 10, 6))
+        assert (got[i] == want).all(), f"frame {i}"
+    assert (got[0] != got[1]).any()
