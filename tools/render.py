@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Render a workload (or an orbit of it) with the HIP library and write PNG files.
+
+    python tools/render.py cfg2_julia_1080p out.png
+    python tools/render.py cfg5_sierpinski_8k_orbit frames/orbit_%03d.png --frames 0 30 60 --scale 0.25
+"""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import kifs_raymarching_amd as K  # noqa: E402
+from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera  # noqa: E402
+from kifs_raymarching_amd.image import write_png  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("workload", choices=sorted(WORKLOADS))
+ap.add_argument("out")
+ap.add_argument("--frames", type=int, nargs="*", default=None, help="orbit frame indices (out needs %%d)")
+ap.add_argument("--scale", type=float, default=1.0, help="resolution scale")
+ap.add_argument("--heatmap", action="store_true")
+args = ap.parse_args()
+w = WORKLOADS[args.workload]
+screen = K.ScreenData(max(1, int(w.screen.width * args.scale)), max(1, int(w.screen.height * args.scale)))
+gui = w.gui
+if args.heatmap:
+    gui = K.GuiData(**{**gui.__dict__, "is_heatmap": True, "fractal_color": (255, 255, 255)})
+with K.GraphicState(0, screen_data=screen, camera_data=w.camera, gui_data=gui) as gs:
+    gs.set_iters(*w.iters)
+    if args.frames is None:
+        write_png(args.out, gs.render())
+        print(f"{args.out}: {screen.width}x{screen.height}, kernel {gs.last_kernel_ms():.3f} ms")
+    else:
+        for k in args.frames:
+            gs.set_camera(orbit_camera(w, k))
+            path = args.out % k
+            write_png(path, gs.render())
+            print(f"{path}: frame {k}, kernel {gs.last_kernel_ms():.3f} ms")
