@@ -108,6 +108,24 @@ float squared_threshold(float T) {
     return v;
 }
 
+// Exact squared form of `norm < T`: returns the smallest binary32 v with sqrtf(v) >= T, so
+// that norm < T  <=>  n2 < v  (n2 >= +0 or NaN).
+float squared_lower_threshold(float T) {
+    if (T != T || T <= 0.0f) return 0.0f;  // norm < T is never true
+    if (T == INFINITY) return INFINITY;    // true for every finite norm
+    double sq = double(T) * double(T);
+    float v = sq >= double(FLT_MAX) ? FLT_MAX : float(sq);
+    while (std::sqrt(v) < T) {
+        if (v == FLT_MAX) return INFINITY;
+        v = std::nextafterf(v, INFINITY);
+    }
+    for (;;) {
+        float down = std::nextafterf(v, -INFINITY);
+        if (down >= 0.0f && std::sqrt(down) >= T) v = down; else break;
+    }
+    return v;
+}
+
 int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     int w, h;
     int st = frame_dims(c, &w, &h);
@@ -135,6 +153,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->bound_n2 = squared_threshold(2.0f + o.epsilon);
     P->orbit_blocks = c->sdf_iters / 6;
     P->orbit_rem = c->sdf_iters % 6;
+    P->fold_n2_stop = squared_lower_threshold(o.max_distance);
     P->width = w;
     P->y0 = 0;
     P->y1 = h;

@@ -30,6 +30,9 @@ struct FrameParams {
     // exactly `dot(p,p) > bound_n2` because correctly rounded sqrt is monotone.
     float bound_n2;
     int orbit_blocks, orbit_rem;        // sdf_iters = 6 * orbit_blocks + orbit_rem
+    // Smallest f32 v with sqrt(v) >= max_distance: `length(pos) < max_distance` (kifs.wgsl:72)
+    // is exactly `dot(pos,pos) < fold_n2_stop`.
+    float fold_n2_stop;
     int width, y0, y1;                  // frame width, row band [y0, y1)
     int encode;                         // KifsEncode
     uint32_t pitch_words;               // output row pitch in 32-bit words

@@ -238,15 +238,17 @@ KIFS_DEV V3 tetrahedral_fold(V3 p) {  // kifs.wgsl:56-66
 }
 
 KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p) {  // kifs.wgsl:68-81
+    // The loop condition `r < max_distance` is evaluated on the squared norm (exact: see
+    // FrameParams::fold_n2_stop), so the square root is taken once, after the loop.
     float scale = 1.0f;
-    float r = length(p);
-    for (int i = 0; i < P.fold_iters && r < P.max_distance; ++i) {
+    float n2 = dot(p, p);
+    for (int i = 0; i < P.fold_iters && n2 < P.fold_n2_stop; ++i) {
         p = tetrahedral_fold(p);
         scale = scale * 2.0f;
         p = V3{fmaf_(2.0f, p.x, -1.0f), fmaf_(2.0f, p.y, -1.0f), fmaf_(2.0f, p.z, -1.0f)};
-        r = length(p);
+        n2 = dot(p, p);
     }
-    return (r - 2.0f) / scale;
+    return (sqrt_(n2) - 2.0f) / scale;
 }
 
 KIFS_DEV V4 mat4_vec(const float* m, V4 v) {  // column-major 4x4 times vector
