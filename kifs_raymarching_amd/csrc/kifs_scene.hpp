@@ -221,13 +221,15 @@ KIFS_DEV V3 genjulia_normal(const FrameParams& P, V3 p) {
 // ---- KIFS ------------------------------------------------------------------------
 // Mirror in a plane through the origin with normal e_a + e_b (kifs.wgsl:6-14 with the
 // normals of :58-62): signed distance (pa+pb)/|n|, reflect only from the negative side.
-KIFS_DEV void mirror2(float& pa, float& pb) {
-    const float len = sqrt_(2.0f);
-    const float nn = 1.0f / len;
-    float sd = (pa + pb) / len;
+KIFS_DEV void mirror_apply(float sd, float& pa, float& pb) {
+    const float nn = 1.0f / sqrt_(2.0f);
     float k = 2.0f * min_(sd, 0.0f);
     pa = fmaf_(-k, nn, pa);
     pb = fmaf_(-k, nn, pb);
+}
+
+KIFS_DEV void mirror2(float& pa, float& pb) {
+    mirror_apply((pa + pb) / sqrt_(2.0f), pa, pb);
 }
 
 KIFS_DEV V3 tetrahedral_fold(V3 p) {  // kifs.wgsl:56-66
@@ -237,15 +239,49 @@ KIFS_DEV V3 tetrahedral_fold(V3 p) {  // kifs.wgsl:56-66
     return p;
 }
 
+// x / sqrt(2) with the reciprocal folded into constants: two residual corrections around
+// x * (1/c).  tools/verify/div_const2.c checks all 2^32 inputs: bit-identical to the correctly
+// rounded quotient for every 2^-102 <= |x| < 2^127 (and for NaN); it is NOT exact for tinier
+// values, zeros and infinities, which is what fold_fast_ok() screens for.
+KIFS_DEV float div_sqrt2_ranged(float x) {
+    const float c = sqrt_(2.0f);
+    const float inv = 1.0f / c;
+    float q0 = x * inv;
+    float e1 = fmaf_(-c, q0, x);
+    float q1 = fmaf_(e1, inv, q0);
+    float e2 = fmaf_(-c, q1, x);
+    return fmaf_(e2, inv, q1);
+}
+
+// The fold with the ranged division; `lo`/`hi` receive min/max |x| over the three quotients'
+// numerators so that the caller can validate the whole fold with two compares.  (min3/max3
+// skip NaN operands, which is fine: a NaN coordinate gives a NaN estimate on either path.)
+KIFS_DEV V3 tetrahedral_fold_ranged(V3 p, float& lo, float& hi) {
+    float x1 = p.x + p.y;
+    mirror_apply(div_sqrt2_ranged(x1), p.x, p.y);
+    float x2 = p.y + p.z;
+    mirror_apply(div_sqrt2_ranged(x2), p.y, p.z);
+    float x3 = p.x + p.z;
+    mirror_apply(div_sqrt2_ranged(x3), p.x, p.z);
+    lo = __builtin_fminf(__builtin_fminf(abs_(x1), abs_(x2)), abs_(x3));
+    hi = __builtin_fmaxf(__builtin_fmaxf(abs_(x1), abs_(x2)), abs_(x3));
+    return p;
+}
+
 KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p) {  // kifs.wgsl:68-81
     // The loop condition `r < max_distance` is evaluated on the squared norm (exact: see
     // FrameParams::fold_n2_stop), so the square root is taken once, after the loop.
     float scale = 1.0f;
     float n2 = dot(p, p);
     for (int i = 0; i < P.fold_iters && n2 < P.fold_n2_stop; ++i) {
-        p = tetrahedral_fold(p);
+        float lo, hi;
+        V3 f = tetrahedral_fold_ranged(p, lo, hi);
+        const bool in_range = (lo >= 0x1p-102f) && (hi < 0x1p127f);
+        // a lane outside the verified range (practically never) sends the wave through the
+        // fold with true divisions; for every in-range lane the two folds agree bit for bit
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!in_range) != 0ull, 0)) f = tetrahedral_fold(p);
+        p = V3{fmaf_(2.0f, f.x, -1.0f), fmaf_(2.0f, f.y, -1.0f), fmaf_(2.0f, f.z, -1.0f)};
         scale = scale * 2.0f;
-        p = V3{fmaf_(2.0f, p.x, -1.0f), fmaf_(2.0f, p.y, -1.0f), fmaf_(2.0f, p.z, -1.0f)};
         n2 = dot(p, p);
     }
     return (sqrt_(n2) - 2.0f) / scale;

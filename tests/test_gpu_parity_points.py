@@ -21,6 +21,11 @@ def points(n, seed, radius=2.5):
     p = rng.uniform(-radius, radius, size=(n, 3)).astype(F)
     p[:8] = [[0, 0, 0], [1, 1, 1], [5, 0, 0], [0.3, 0.2, 0.1], [1e-30, 0, 0], [-0.0, 0.0, 2.0],
              [1e20, 1e20, 0], [0.5, -0.25, 0.125]]
+    # inputs that leave the verified range of the constant-division shortcut in the fold
+    # (exact cancellation, tiny and denormal sums, infinities, NaN) and must take the exact path
+    p[8:20] = [[0.25, -0.25, 0.7], [0.7, 0.25, -0.25], [-0.25, 0.7, 0.25], [1e-35, 1e-36, 0.4],
+               [-1e-40, 0.0, 0.0], [1e-45, -1e-45, 1e-45], [np.inf, 0.0, 0.0], [0.0, -np.inf, 1.0],
+               [np.nan, 0.5, 0.5], [0.5, 0.5, np.nan], [-0.0, -0.0, -0.0], [3e38, 3e38, 0.0]]
     return p
 
 
