@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall-clock budget of the cpu_baseline sample (0 disables it)")
     ap.add_argument("--encode", type=int, default=1, help="1 = sRGB target (reference default), 0 = UNORM")
+    ap.add_argument("--orbit", action="store_true",
+                    help="move the camera every frame (phi = 2*pi*frame/frames of the workload, "
+                         "host camera model + 64-byte uniform update per step) instead of re-rendering one view")
     ap.add_argument("--shard", default="frames", choices=["frames", "bands"],
                     help="N > 1: whole frames per rank (throughput, default) or row bands of each frame (latency)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -110,7 +113,7 @@ def main():
 
     import kifs_raymarching_amd as K
     from kifs_raymarching_amd.bands import BandFrame, FrameStream
-    from kifs_raymarching_amd.configs import HEADLINE, WORKLOADS
+    from kifs_raymarching_amd.configs import HEADLINE, WORKLOADS, orbit_camera
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,13 +149,20 @@ def main():
         bf = FrameStream(W, H, rank, world, device)
         rows0 = H
 
-        def render_band(out, frame_index):  # every frame of the synthetic sequence is the same view
+        def render_band(out, frame_index):  # without --orbit every frame is the same view
+            if args.orbit:
+                gs.set_camera(orbit_camera(w, frame_index % max(w.frames, 120)))
             gs.render_async(out, stream=stream, y0=0, y1=H, encode=args.encode)
     else:
         bf = BandFrame(W, H, rank, world, device)
         rows0 = bf.y1 - bf.y0
 
+        orbit_frame = [0]
+
         def render_band(out, y0, y1):
+            if args.orbit:
+                gs.set_camera(orbit_camera(w, orbit_frame[0] % max(w.frames, 120)))
+                orbit_frame[0] += 1
             gs.render_async(out, stream=stream, y0=y0, y1=y1, encode=args.encode)
 
     def barrier():
@@ -227,6 +237,7 @@ def main():
                        "max_iterations": w.gui.max_iterations, "sdf_iters": w.iters[0],
                        "normal_iters": w.iters[1], "fold_iters": w.iters[2],
                        "encode": "srgb8" if args.encode else "unorm8",
+                       "camera": "orbit, one pose per frame" if args.orbit else "fixed",
                        "parallelism": "1 GPU, one launch per frame" if world == 1 else
                        (f"{world} GPUs x whole frames (frame-parallel), one process per GPU, "
                         "finished frames sent to rank 0 by grouped RCCL p2p" if frames_mode else

@@ -146,6 +146,30 @@ int kifs_render_async(kifs_ctx* ctx, void* hip_stream, uint8_t* dev_out_rgba8,
  * of `world` owns rows [y0, y1); bands differ by at most one row. */
 int kifs_band_range(int height, int rank, int world, int* y0, int* y1);
 
+/* ---- single-process multi-GPU ------------------------------------------------------
+ * For a host that drives all GPUs of a node from one process (the reference's host is one
+ * process, application.rs:37-48).  A kifs_multi owns one context per listed device; a render
+ * splits the frame into kifs_band_range row bands, launches every band on its own device
+ * concurrently and collects them into the frame on the ROOT device (the first one listed) by
+ * peer-to-peer copies over xGMI (hipMemcpyPeerAsync; the root renders its band in place).
+ * Bands are bit-identical to the same rows of a single-GPU frame.  The multi-process form of
+ * the same sharding (one process per GPU, RCCL point-to-point gather) lives above the ABI in
+ * kifs_raymarching_amd/bands.py.  A device may be listed more than once (testing on one GPU). */
+typedef struct kifs_multi kifs_multi;
+kifs_multi* kifs_multi_create(const int* device_ordinals, int n_devices, int* status);
+void kifs_multi_destroy(kifs_multi* m);
+int kifs_multi_set_screen(kifs_multi* m, const KifsScreenUniform* screen);
+int kifs_multi_set_camera(kifs_multi* m, const KifsCameraUniform* camera);
+int kifs_multi_set_options(kifs_multi* m, const KifsOptionsUniform* options);
+int kifs_multi_set_iters(kifs_multi* m, int sdf_iters, int normal_iters, int fold_iters);
+/* `out_rgba8`: host memory or device memory of the root device; full frame, `pitch_bytes`
+ * per row.  Returns when the frame is complete. */
+int kifs_multi_render(kifs_multi* m, uint8_t* out_rgba8, size_t pitch_bytes, int encode);
+/* Band i of the last configured screen: device ordinal and rows [y0, y1). */
+int kifs_multi_band(kifs_multi* m, int i, int* device_ordinal, int* y0, int* y1);
+/* Kernel time of band i in the last kifs_multi_render, ms (load balance across bands). */
+double kifs_multi_band_ms(kifs_multi* m, int i);
+
 /* Device time of the most recent kifs_render on this context in ms (HIP events
  * on the launch stream), or a negative value if none completed. */
 double kifs_last_kernel_ms(kifs_ctx* ctx);

@@ -69,6 +69,15 @@ SIGNATURES = {
     "kifs_render_async": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                     C.c_int]),
     "kifs_band_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "kifs_multi_create": (_ctx, [_P(C.c_int), C.c_int, _P(C.c_int)]),
+    "kifs_multi_destroy": (None, [_ctx]),
+    "kifs_multi_set_screen": (C.c_int, [_ctx, _P(ScreenUniform)]),
+    "kifs_multi_set_camera": (C.c_int, [_ctx, _P(CameraUniform)]),
+    "kifs_multi_set_options": (C.c_int, [_ctx, _P(OptionsUniform)]),
+    "kifs_multi_set_iters": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
+    "kifs_multi_render": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_int]),
+    "kifs_multi_band": (C.c_int, [_ctx, C.c_int, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
+    "kifs_multi_band_ms": (C.c_double, [_ctx, C.c_int]),
     "kifs_last_kernel_ms": (C.c_double, [_ctx]),
     "kifs_synchronize": (C.c_int, [_ctx]),
     "kifs_strerror": (C.c_char_p, [C.c_int]),

@@ -65,5 +65,6 @@ HEADLINE = "cfg2_julia_1080p"
 def orbit_camera(workload: Workload, frame: int) -> CameraData:
     """Frame k of the cfg-5 orbit: phi_k = 2*pi*k/frames, fixed theta and distance."""
     base = workload.camera
+    frames = max(workload.frames, 120)
     return CameraData(origin_distance=base.origin_distance, min_distance=base.min_distance,
-                      phi=2.0 * math.pi * frame / workload.frames, theta=base.theta)
+                      phi=2.0 * math.pi * frame / frames, theta=base.theta)

@@ -563,6 +563,197 @@ int kifs_eval_math(kifs_ctx* c, int fn, const float* in, float param, float* out
 
 }  // extern "C"
 
+// ---- single-process multi-GPU ------------------------------------------------------------
+struct kifs_multi {
+    std::vector<kifs_ctx*> ctx;
+    std::vector<int> dev;
+    std::vector<uint8_t*> band;        // per-device band buffer (non-root)
+    std::vector<size_t> band_bytes;
+    std::vector<hipEvent_t> ev0, ev1;  // kernel start/stop on each device's stream
+    std::vector<double> band_ms;
+    uint8_t* root_frame = nullptr;     // staging frame on the root when the destination is host memory
+    size_t root_frame_bytes = 0;
+};
+
+extern "C" {
+
+void kifs_multi_destroy(kifs_multi* m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        if (!m->ctx[i]) continue;
+        DeviceGuard g(m->dev[i]);
+        (void)hipStreamSynchronize(m->ctx[i]->stream);
+        if (i < m->band.size() && m->band[i]) (void)hipFree(m->band[i]);
+        if (i < m->ev0.size() && m->ev0[i]) (void)hipEventDestroy(m->ev0[i]);
+        if (i < m->ev1.size() && m->ev1[i]) (void)hipEventDestroy(m->ev1[i]);
+    }
+    if (m->root_frame) {
+        DeviceGuard g(m->dev[0]);
+        (void)hipFree(m->root_frame);
+    }
+    for (kifs_ctx* c : m->ctx) kifs_destroy(c);
+    delete m;
+}
+
+kifs_multi* kifs_multi_create(const int* devices, int n, int* status) {
+    auto fail = [&](int st, kifs_multi* m) -> kifs_multi* {
+        if (status) *status = st;
+        kifs_multi_destroy(m);
+        return nullptr;
+    };
+    if (!devices || n <= 0 || n > 64) return fail(KIFS_ERR_BAD_ARG, nullptr);
+    kifs_multi* m = new (std::nothrow) kifs_multi();
+    if (!m) return fail(KIFS_ERR_DEVICE_INIT, nullptr);
+    m->band.assign(size_t(n), nullptr);
+    m->band_bytes.assign(size_t(n), 0);
+    m->ev0.assign(size_t(n), nullptr);
+    m->ev1.assign(size_t(n), nullptr);
+    m->band_ms.assign(size_t(n), -1.0);
+    for (int i = 0; i < n; ++i) {
+        int st = KIFS_OK;
+        kifs_ctx* c = kifs_create(devices[i], &st);
+        if (!c) return fail(st, m);
+        m->ctx.push_back(c);
+        m->dev.push_back(devices[i]);
+        DeviceGuard g(devices[i]);
+        if (hipEventCreate(&m->ev0[size_t(i)]) != hipSuccess || hipEventCreate(&m->ev1[size_t(i)]) != hipSuccess)
+            return fail(KIFS_ERR_DEVICE_INIT, m);
+        if (devices[i] != devices[0]) {  // direct xGMI access both ways; failure only means staged copies
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can)
+                (void)hipDeviceEnablePeerAccess(devices[0], 0);
+            (void)hipGetLastError();
+        }
+    }
+    if (status) *status = KIFS_OK;
+    return m;
+}
+
+#define KIFS_MULTI_FORWARD(call)                 \
+    if (!m) return KIFS_ERR_BAD_ARG;             \
+    for (kifs_ctx* c : m->ctx) {                 \
+        int st = (call);                         \
+        if (st != KIFS_OK) return st;            \
+    }                                            \
+    return KIFS_OK;
+
+int kifs_multi_set_screen(kifs_multi* m, const KifsScreenUniform* s) { KIFS_MULTI_FORWARD(kifs_set_screen(c, s)) }
+int kifs_multi_set_camera(kifs_multi* m, const KifsCameraUniform* cam) { KIFS_MULTI_FORWARD(kifs_set_camera(c, cam)) }
+int kifs_multi_set_options(kifs_multi* m, const KifsOptionsUniform* o) { KIFS_MULTI_FORWARD(kifs_set_options(c, o)) }
+int kifs_multi_set_iters(kifs_multi* m, int a, int b, int f) { KIFS_MULTI_FORWARD(kifs_set_iters(c, a, b, f)) }
+
+int kifs_multi_band(kifs_multi* m, int i, int* device, int* y0, int* y1) {
+    if (!m || i < 0 || size_t(i) >= m->ctx.size() || !y0 || !y1) return KIFS_ERR_BAD_ARG;
+    int w, h;
+    if (!m->ctx[0]->have_screen) return KIFS_ERR_UNCONFIGURED;
+    int st = frame_dims(m->ctx[0], &w, &h);
+    if (st != KIFS_OK) return st;
+    if (device) *device = m->dev[size_t(i)];
+    return kifs_band_range(h, i, int(m->ctx.size()), y0, y1);
+}
+
+double kifs_multi_band_ms(kifs_multi* m, int i) {
+    return (m && i >= 0 && size_t(i) < m->band_ms.size()) ? m->band_ms[size_t(i)] : -1.0;
+}
+
+int kifs_multi_render(kifs_multi* m, uint8_t* out, size_t pitch, int encode) {
+    if (!m || !out) return KIFS_ERR_BAD_ARG;
+    kifs_ctx* root = m->ctx[0];
+    if (!root->have_screen || !root->have_camera || !root->have_options) return KIFS_ERR_UNCONFIGURED;
+    int w, h;
+    int st = frame_dims(root, &w, &h);
+    if (st != KIFS_OK) return st;
+    const size_t row_bytes = size_t(w) * 4;
+    if (pitch < row_bytes || (pitch & 3u)) return KIFS_ERR_BAD_SIZE;
+    const int n = int(m->ctx.size());
+    // the frame the bands are collected into: the caller's buffer if it is root-device memory
+    uint8_t* frame = out;
+    size_t fpitch = pitch;
+    bool host_dst;
+    {
+        DeviceGuard g(m->dev[0]);
+        host_dst = !is_device_pointer(out);
+        if (host_dst) {
+            const size_t need = row_bytes * size_t(h);
+            if (need > m->root_frame_bytes) {
+                if (m->root_frame) (void)hipFree(m->root_frame);
+                m->root_frame = nullptr;
+                m->root_frame_bytes = 0;
+                if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&m->root_frame), need), "hipMalloc(multi frame)"))
+                    return KIFS_ERR_RUNTIME;
+                m->root_frame_bytes = need;
+            }
+            frame = m->root_frame;
+            fpitch = row_bytes;
+        }
+    }
+    // 1. launch every band on its own device
+    for (int i = 0; i < n; ++i) {
+        int y0, y1;
+        kifs_band_range(h, i, n, &y0, &y1);
+        kifs_ctx* c = m->ctx[size_t(i)];
+        DeviceGuard g(m->dev[size_t(i)]);
+        uint8_t* dst;
+        size_t dpitch;
+        if (i == 0) {
+            dst = frame + size_t(y0) * fpitch;
+            dpitch = fpitch;
+        } else {
+            const size_t need = row_bytes * size_t(y1 - y0);
+            if (need > m->band_bytes[size_t(i)]) {
+                if (m->band[size_t(i)]) (void)hipFree(m->band[size_t(i)]);
+                m->band[size_t(i)] = nullptr;
+                m->band_bytes[size_t(i)] = 0;
+                if (need && !hip_ok(hipMalloc(reinterpret_cast<void**>(&m->band[size_t(i)]), need), "hipMalloc(band)"))
+                    return KIFS_ERR_RUNTIME;
+                m->band_bytes[size_t(i)] = need;
+            }
+            dst = m->band[size_t(i)];
+            dpitch = row_bytes;
+        }
+        if (hipEventRecord(m->ev0[size_t(i)], c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+        if (y1 > y0) {
+            st = enqueue(c, c->stream, dst, dpitch, y0, y1, encode);
+            if (st != KIFS_OK) return st;
+        }
+        if (hipEventRecord(m->ev1[size_t(i)], c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+    }
+    // 2. the root pulls each finished band into its frame over xGMI, in band order
+    {
+        DeviceGuard g(m->dev[0]);
+        for (int i = 1; i < n; ++i) {
+            int y0, y1;
+            kifs_band_range(h, i, n, &y0, &y1);
+            if (y1 <= y0) continue;
+            if (hipStreamWaitEvent(root->stream, m->ev1[size_t(i)], 0) != hipSuccess) return KIFS_ERR_RUNTIME;
+            hipError_t e;
+            if (fpitch == row_bytes) {
+                e = hipMemcpyPeerAsync(frame + size_t(y0) * fpitch, m->dev[0], m->band[size_t(i)],
+                                       m->dev[size_t(i)], row_bytes * size_t(y1 - y0), root->stream);
+            } else {  // padded destination rows: 2-D copy (unified addressing resolves the peer)
+                e = hipMemcpy2DAsync(frame + size_t(y0) * fpitch, fpitch, m->band[size_t(i)], row_bytes,
+                                     row_bytes, size_t(y1 - y0), hipMemcpyDeviceToDevice, root->stream);
+            }
+            if (!hip_ok(e, "peer copy of a band")) return KIFS_ERR_COMM;
+        }
+        if (host_dst &&
+            !hip_ok(hipMemcpy2DAsync(out, pitch, frame, fpitch, row_bytes, size_t(h), hipMemcpyDeviceToHost,
+                                     root->stream), "frame to host"))
+            return KIFS_ERR_RUNTIME;
+        if (!hip_ok(hipStreamSynchronize(root->stream), "multi sync")) return KIFS_ERR_RUNTIME;
+    }
+    for (int i = 0; i < n; ++i) {
+        DeviceGuard g(m->dev[size_t(i)]);
+        if (hipStreamSynchronize(m->ctx[size_t(i)]->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
+        float ms = 0.0f;
+        m->band_ms[size_t(i)] =
+            hipEventElapsedTime(&ms, m->ev0[size_t(i)], m->ev1[size_t(i)]) == hipSuccess ? double(ms) : -1.0;
+    }
+    return KIFS_OK;
+}
+
+}  // extern "C"
+
 // ---- sRGB threshold table ---------------------------------------------------------------
 namespace kifs {
 

@@ -339,6 +339,67 @@ class GraphicState:
         return out
 
 
+class MultiGraphicState:
+    """Single-process multi-GPU renderer over kifs_multi_* (one context per device, bands
+    collected on the first device by peer-to-peer copies)."""
+
+    def __init__(self, devices, screen_data: ScreenData, camera_data: CameraData = None,
+                 gui_data: GuiData = None, iters=(100, 10, 10)):
+        arr = (C.c_int * len(devices))(*devices)
+        st = C.c_int(0)
+        self._m = lib.kifs_multi_create(arr, len(devices), C.byref(st))
+        if not self._m:
+            raise KifsError(st.value, f"kifs_multi_create({list(devices)})")
+        self.devices = list(devices)
+        self.screen_data = screen_data
+        u = screen_data.into_buffer_data()
+        check(lib.kifs_multi_set_screen(self._m, C.byref(u)), "multi set_screen")
+        self.set_camera(camera_data or CameraData())
+        self.update_options(gui_data or GuiData())
+        check(lib.kifs_multi_set_iters(self._m, *iters), "multi set_iters")
+
+    def set_camera(self, camera_data: CameraData):
+        u = camera_data.into_buffer_data()
+        check(lib.kifs_multi_set_camera(self._m, C.byref(u)), "multi set_camera")
+
+    def update_options(self, gui_data: GuiData):
+        u = gui_data.into_buffer_data()
+        check(lib.kifs_multi_set_options(self._m, C.byref(u)), "multi set_options")
+
+    def render(self, out=None, encode: int = ENCODE_SRGB, pitch_bytes: int = None):
+        w, h = self.screen_data.width, self.screen_data.height
+        if out is None:
+            out = np.empty((h, w, 4), dtype=np.uint8)
+        ptr = out.ctypes.data if isinstance(out, np.ndarray) else _device_pointer(out)
+        check(lib.kifs_multi_render(self._m, ptr, pitch_bytes or w * 4, encode), "multi render")
+        return out
+
+    def bands(self):
+        res = []
+        for i in range(len(self.devices)):
+            d, y0, y1 = C.c_int(), C.c_int(), C.c_int()
+            check(lib.kifs_multi_band(self._m, i, C.byref(d), C.byref(y0), C.byref(y1)))
+            res.append((d.value, y0.value, y1.value, float(lib.kifs_multi_band_ms(self._m, i))))
+        return res
+
+    def close(self):
+        if getattr(self, "_m", None):
+            lib.kifs_multi_destroy(self._m)
+            self._m = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def band_range(height: int, rank: int, world: int):
     y0, y1 = C.c_int(), C.c_int()
     check(lib.kifs_band_range(height, rank, world, C.byref(y0), C.byref(y1)), "band_range")

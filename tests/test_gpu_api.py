@@ -162,3 +162,26 @@ def test_orbit_frames_match_oracle(gs, kifs, oracle):
         got = gpu_frame(gs, screen, cam, w.gui, w.iters)
         want = oracle_frame(oracle, kifs, screen, cam, w.gui, w.iters)
         assert (got == want).all(), k
+
+
+def test_single_process_multi_device_render(kifs, oracle):
+    """kifs_multi_*: one context per listed device, bands collected on the root by peer copies.
+    On a one-GPU box the device is listed several times; the frame must equal the oracle's."""
+    import torch
+    screen, cam = kifs.ScreenData(200, 135), kifs.CameraData(origin_distance=3.2, phi=0.4)
+    gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2))
+    want = oracle_frame(oracle, kifs, screen, cam, gui, (12, 10, 10))
+    for n in (1, 2, 5):
+        with kifs.MultiGraphicState([0] * n, screen, cam, gui, iters=(12, 10, 10)) as mg:
+            assert (mg.render() == want).all(), n                       # host destination
+            dev = torch.zeros((135, 200, 4), dtype=torch.uint8, device="cuda:0")
+            mg.render(out=dev)                                          # root-device destination
+            assert (dev.cpu().numpy() == want).all(), n
+            padded = torch.full((135, 200 * 4 + 64), 7, dtype=torch.uint8, device="cuda:0")
+            mg.render(out=padded, pitch_bytes=200 * 4 + 64)             # padded rows
+            got = padded.cpu().numpy()
+            assert (got[:, :800].reshape(135, 200, 4) == want).all() and (got[:, 800:] == 7).all()
+            bands = mg.bands()
+            assert bands[0][1] == 0 and bands[-1][2] == 135 and all(b[3] > 0 for b in bands)
+    with pytest.raises(kifs.KifsError):
+        kifs.MultiGraphicState([0, 4096], screen)
