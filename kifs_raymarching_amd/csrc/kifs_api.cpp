@@ -151,6 +151,10 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->normal_iters = c->normal_iters;
     P->fold_iters = c->fold_iters;
     P->bound_n2 = squared_threshold(2.0f + o.epsilon);
+    {   // culls need a sane sphere radius R = 2 + epsilon > 0 and a positive epsilon test
+        const float R = 2.0f + o.epsilon;
+        P->cull_n2 = (R > 0.5f && R < 1.0e6f && o.epsilon >= 0.0f) ? 1.1f * R * R : 0.0f;
+    }
     P->orbit_blocks = c->sdf_iters / 6;
     P->orbit_rem = c->sdf_iters % 6;
     P->fold_n2_stop = squared_lower_threshold(o.max_distance);
@@ -164,6 +168,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->tile_order = nullptr;
     P->tile_count = 0;
     P->counters = c->d_counters;
+    P->workgroups_per_cu = 0;
     return KIFS_OK;
 }
 
@@ -228,6 +233,34 @@ const TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) 
     return slot;
 }
 
+// Residency rule for the Julia pipelines.  The long rays of a frame slow each other down as soon
+// as they share a SIMD (~1490 cycles per march step alone, ~1570 with one neighbour, ~1900 with
+// seven), and after the bounding-sphere culls nothing else needs the slots: the only tiles
+// with real work are those the projected bounding sphere covers.  If those are few enough to be
+// spread over the 256 CUs in a couple of rounds, capping residency lets every long wave run
+// near its lone-wave speed (1080p, camera at distance 5: 207 -> 172 us at one workgroup per
+// CU); if they are many (4096^2, or a camera close to the fractal) the frame is bound by their
+// aggregate instruction throughput and full residency wins (4096^2: 0.70 ms vs 1.95 ms capped).
+int residency_for(const kifs::FrameParams& P, uint32_t group, int frame_height, uint32_t tile_count) {
+    if (group == kifs::GROUP_KIFS || P.cull_n2 <= 0.0f || P.is_heatmap) return 0;
+    const double R2 = double(P.cull_n2) / 1.1;  // (2 + epsilon)^2
+    const double d2 = double(P.origin.x) * P.origin.x + double(P.origin.y) * P.origin.y +
+                      double(P.origin.z) * P.origin.z;
+    const double frame_px = double(P.width) * double(frame_height);
+    double disk_px = frame_px;  // camera inside the sphere: everything is a candidate
+    if (d2 > R2 * 1.0001) {
+        const double r_uv = std::sqrt(R2 / (d2 - R2));          // tangent of the sphere's angular radius
+        const double r_px = r_uv * 0.5 * double(frame_height);  // focal length 1, uv.y in [-1, 1]
+        disk_px = std::min(frame_px, 3.14159265358979 * r_px * r_px);
+    }
+    // a band of a frame gets its share of the disk
+    const double band_share = frame_px > 0 ? double(tile_count) * (kifs::TILE_W * kifs::TILE_H) / frame_px : 1.0;
+    const double disk_tiles = disk_px * std::min(1.0, band_share) / (kifs::TILE_W * kifs::TILE_H);
+    if (disk_tiles <= 1024.0) return 1;
+    if (disk_tiles <= 2048.0) return 2;
+    return 0;
+}
+
 int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int y0, int y1,
             int encode) {
     hip_ok(hipGetLastError(), "stale error before enqueue");
@@ -252,6 +285,7 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
     if (!tt) return KIFS_ERR_RUNTIME;
     P.tile_order = tt->d_order;
     P.tile_count = tt->count;
+    P.workgroups_per_cu = residency_for(P, c->options.fractal_group_id, h, tt->count);
     hipError_t e = kifs::launch_render(P, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
     return hip_ok(e, "render_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;

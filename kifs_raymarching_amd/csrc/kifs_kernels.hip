@@ -78,23 +78,20 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
 }
 
 // Dynamic LDS requested only to cap how many workgroups share a CU (the kernel never touches
-// it).  A Julia frame is bound by the latency of its longest rays, and those slow each other
-// down badly once three or more share a SIMD (measured: ~1490 ticks per march step alone,
-// ~1700 at 3 waves/SIMD, ~1900 at 8), while the dispatcher happily co-locates them.  For a
-// frame small enough that the rest of its work hides in the shadow of those rays, two
-// workgroups per CU is the best trade (1080p: 213 -> 183 us); a large frame is throughput
-// bound and keeps full residency (4096^2: 0.71 ms vs 1.31 ms capped).
-// KIFS_LDS_PAD=<bytes> overrides the rule (tuning).
-constexpr unsigned TWO_PER_CU_PAD = 72 * 1024;    // 2 KiB static + 72 KiB: two fit in 160 KiB, three do not
-constexpr unsigned SMALL_FRAME_TILES = 16384;     // 32x8-pixel tiles: about 4.2 Mpixel
-
-static unsigned residency_pad_bytes(int group, unsigned tile_count) {
+// it); the cap itself is decided on the host (residency_for() in kifs_api.cpp).
+// KIFS_LDS_PAD=<bytes> overrides it (tuning).
+static unsigned residency_pad_bytes(int workgroups_per_cu) {
     static const long forced = [] {
         const char* e = std::getenv("KIFS_LDS_PAD");
         return e ? std::strtol(e, nullptr, 10) : -1L;
     }();
     if (forced >= 0) return unsigned(forced);
-    return (group == GROUP_JULIA && tile_count <= SMALL_FRAME_TILES) ? TWO_PER_CU_PAD : 0u;
+    switch (workgroups_per_cu) {  // static LDS is 2 KiB; a CU has 160 KiB
+    case 1: return 100 * 1024;
+    case 2: return 72 * 1024;
+    case 3: return 50 * 1024;
+    default: return 0;
+    }
 }
 
 // Pipeline selection: the reference keeps three render pipelines and picks one per
@@ -102,7 +99,7 @@ static unsigned residency_pad_bytes(int group, unsigned tile_count) {
 // primitive_id per SDF call (kifs.wgsl:139-155).  Here both are template parameters.
 template <int GROUP, int PRIM>
 static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
-    const unsigned pad = residency_pad_bytes(GROUP, P.tile_count);
+    const unsigned pad = residency_pad_bytes(P.workgroups_per_cu);
     if (pad > 48 * 1024) {  // beyond the default dynamic-LDS limit: opt in once per kernel
         static const hipError_t attr = hipFuncSetAttribute(
             reinterpret_cast<const void*>(&render_kernel<GROUP, PRIM>),

@@ -30,6 +30,8 @@ struct FrameParams {
     // exactly `dot(p,p) > bound_n2` because correctly rounded sqrt is monotone.
     float bound_n2;
     int orbit_blocks, orbit_rem;        // sdf_iters = 6 * orbit_blocks + orbit_rem
+    // (2 + epsilon)^2 * 1.1 for the bounding-sphere culls (0 disables them: NaN/odd epsilon)
+    float cull_n2;
     // Smallest f32 v with sqrt(v) >= max_distance: `length(pos) < max_distance` (kifs.wgsl:72)
     // is exactly `dot(pos,pos) < fold_n2_stop`.
     float fold_n2_stop;
@@ -44,6 +46,9 @@ struct FrameParams {
     // hand-written long-ray loop, [1] wave-steps taken on the general path, [2] entries into
     // the long-ray loop, [3] waves.  Enabled by kifs_debug_counters().
     unsigned long long* counters;
+    // Host-side launch hint, not read by the kernels: how many workgroups may share a CU
+    // (0 = no cap).  See residency_for() in kifs_api.cpp.
+    int workgroups_per_cu;
 };
 
 }  // namespace kifs

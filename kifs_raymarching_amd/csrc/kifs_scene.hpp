@@ -436,6 +436,7 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
         "s_mov_b32 s92, 0x7fffff\n"
         "s_movk_i32 s93, 0x100\n"                              // class mask: +normal
         "s_movk_i32 s94, 0x260\n"                              // class mask: -0, +0, +inf
+        "v_cmp_lt_f32_e64 s[74:75], 0, %[cullv]\n"            // all ones when the culls are enabled
         // ------------------------------------------------------------------ one march step
         "10:\n"
         "v_mul_f32_e32 v52, v32, v32\n"                       // dot(p,p): x*x, +y*y, +z*z
@@ -599,6 +600,16 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
         "s_nop 1\n"
         "v_cndmask_b32_e32 v60, v61, v60, vcc\n"
         "v_add_f32_e32 v54, -2.0, v60\n"                      // d = norm - 2
+        // early ray termination: outside the sphere with margin and heading away from it, the
+        // ray cannot come back inside, so it can never hit: retire the lane as a miss now
+        "v_mul_f32_e32 v55, v32, v35\n"                       // dot(p, dir)
+        "v_fma_f32 v55, v30, v36, v55\n"
+        "v_fma_f32 v55, v31, v37, v55\n"
+        "v_cmp_lt_f32_e32 vcc, %[cull], v52\n"                // n2 > 1.1 R^2 (never when cull = 0 -> see below)
+        "v_cmp_lt_f32_e64 s[80:81], 0, v55\n"                 // moving outwards
+        "s_and_b64 vcc, vcc, s[80:81]\n"
+        "s_and_b64 vcc, vcc, s[74:75]\n"                      // culling enabled?
+        "s_andn2_b64 s[76:77], s[76:77], vcc\n"               // drop them from the live lanes
         "s_mov_b64 exec, s[76:77]\n"
         "s_branch 41b\n"
         "19:\n"                                               // hand the current step to the general loop
@@ -610,10 +621,10 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
         : "{v[36:37]}"(dyz), "{v[38:39]}"(w0), "{v59}"(c1), [oyz] "s"(oyz), [ox] "s"(P.origin.x),
           [eps] "s"(P.epsilon), [maxd] "s"(P.max_distance), [bound] "s"(P.bound_n2), [cyz] "s"(cyz),
           [cw0] "s"(cw0), [c0x] "s"(c0x), [maxit] "s"(P.max_iterations), [blocks] "s"(P.orbit_blocks),
-          [rem] "s"(P.orbit_rem), [lanes] "s"(lanes)
+          [rem] "s"(P.orbit_rem), [lanes] "s"(lanes), [cull] "s"(P.cull_n2), [cullv] "v"(P.cull_n2)
         : "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
           "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62", "v63", "s84",
-          "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s96", "s97", "s76", "s77", "s78",
+          "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s96", "s97", "s74", "s75", "s76", "s77", "s78",
           "s79", "s80", "s81", "s82", "s83");
     const unsigned lane = __lane_id();
     p = V3{px1.x, pyz.x, pyz.y};
@@ -635,6 +646,18 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid) {
     int trips = 0;     // == the loop counter i of entry.wgsl:11 for every marching lane
     int i_final = 0;
     bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
+    // Bounding-sphere cull.  Outside the sphere of radius R = 2 + epsilon the estimate is
+    // length(p) - 2 > epsilon (julia.wgsl:8-9), so a ray that never enters the sphere can never
+    // satisfy `d < epsilon`: its pixel is background whatever else the loop does (only the
+    // heatmap's step count would notice).  The test keeps a 10 % margin on R^2, orders of
+    // magnitude above the rounding of p = fma(t, dir, origin) for any t < max_distance.
+    if (P.is_heatmap == 0u && P.cull_n2 > 0.0f) {
+        const float oo = dot(P.origin, P.origin);
+        const float b = -dot(P.origin, dir);            // parameter of closest approach
+        const float c2 = fmaf_(-b, b, oo);              // squared distance at closest approach
+        const bool never_inside = (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
+        marching = marching && !never_inside;
+    }
     const bool fast_ok = (P.is_heatmap == 0u) && (P.sdf_iters >= 1);  // wave-uniform
     int fast_steps = 0, fast_entries = 0, general_steps = 0;        // diagnostics (SGPRs)
     unsigned long long fast_ticks = 0;
