@@ -415,8 +415,7 @@ KIFS_DEV V3 ray_direction(const FrameParams& P, int x, int y) {
     "v_pk_fma_f32 v[48:49], v[42:43], v[42:43], v[50:51] op_sel_hi:[0,0,1]\n"                 \
     "v_pk_fma_f32 v[44:45], v[44:45], v[44:45], v[48:49] op_sel:[1,1,0] op_sel_hi:[1,1,1] neg_hi:[0,0,1]\n" \
     "v_pk_add_f32 v[44:45], v[44:45], %[c0x]\n"                                               \
-    "v_cmp_lt_f32 vcc, %[maxd], v44\n"                                                        \
-    "s_andn2_b64 exec, exec, vcc\n"
+    "v_cmpx_nlt_f32 vcc, %[maxd], v44\n" /* exec &= !(|q|^2 > max_distance): escaped lanes freeze */
 
 KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit,
                                bool& marching, int& trips, int& outside_steps) {
@@ -427,6 +426,7 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
     const unsigned long long lanes = __builtin_amdgcn_ballot_w64(marching);
     unsigned long long hit_mask = 0, live_out;
     asm volatile(
+        "s_setprio 3\n"   // after the culls only rays that reach the fractal get here: issue them first
         "s_mov_b64 s[84:85], exec\n"
         "s_and_b64 exec, exec, %[lanes]\n"
         "s_mov_b32 s88, 2.0\n"
@@ -548,22 +548,14 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
         "v_add_f32_e32 v34, v34, v54\n"                       // t += d
         "v_fma_f32 v32, v34, v35, %[ox]\n"                    // p = origin + t * dir
         "v_pk_fma_f32 v[30:31], v[34:35], v[36:37], %[oyz] op_sel_hi:[0,1,1]\n"
-        "v_cmp_gt_f32_e32 vcc, %[maxd], v34\n"                // t < max_distance
-        "s_and_b64 exec, exec, vcc\n"                         // the others stop as misses
+        "v_cmpx_gt_f32 vcc, %[maxd], v34\n"                   // t < max_distance; the others stop as misses
         "s_add_u32 %[trips], %[trips], 1\n"
         "s_cbranch_execz 18f\n"
-        "s_cmp_eq_u32 %[trips], 24\n"                        // a ray still marching after 24 steps is
-        "s_cbranch_scc1 50f\n"                               // on the critical path: raise its priority
         "s_cmp_lt_i32 %[trips], %[maxit]\n"
         "s_cbranch_scc1 10b\n"
         "18:\n"                                               // nobody left, or out of iterations
         "s_mov_b64 %[live], 0\n"
         "s_branch 20f\n"
-        "50:\n"
-        "s_setprio 3\n"
-        "s_cmp_lt_i32 %[trips], %[maxit]\n"
-        "s_cbranch_scc1 10b\n"
-        "s_branch 18b\n"
         // ---- remainder trips (sdf_iters % 6), out of the hot line
         "30:\n"
         "s_mov_b32 s97, %[rem]\n"
