@@ -100,11 +100,18 @@ static unsigned residency_pad_bytes(int workgroups_per_cu) {
 template <int GROUP, int PRIM>
 static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
     const unsigned pad = residency_pad_bytes(P.workgroups_per_cu);
-    if (pad > 48 * 1024) {  // beyond the default dynamic-LDS limit: opt in once per kernel
-        static const hipError_t attr = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&render_kernel<GROUP, PRIM>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (attr != hipSuccess) return attr;
+    if (pad > 48 * 1024) {
+        // beyond the default dynamic-LDS limit: opt in once per kernel AND per device (the
+        // attribute belongs to the device's copy of the code object)
+        static bool opted_in[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+        if (dev < 0 || dev >= 64 || !opted_in[dev]) {
+            hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<GROUP, PRIM>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (attr != hipSuccess) return attr;
+            if (dev >= 0 && dev < 64) opted_in[dev] = true;
+        }
     }
     hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), dim3(P.tile_count), dim3(BLOCK), pad, stream, P);
     return hipGetLastError();

@@ -742,25 +742,24 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
     int trips = 0;
     int i_final = 0;
     bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
-    while (__ballot(marching) != 0ull) {
-        // Long-marching waves are the frame's critical path: raise their issue priority as
-        // they age so that co-resident short waves never delay them.
+    while (__builtin_amdgcn_ballot_w64(marching) != 0ull) {
+        // a ray still marching after 32 steps is on the frame's critical path: issue it first
         if (trips == 32) __builtin_amdgcn_s_setprio(3);
         const bool more = (trips + 1) < P.max_iterations;  // scalar
-        if (marching) {
-            float d = scene_sdf<GROUP, PRIM>(P, p);
-            if (d < P.epsilon) {
-                hit = true;          // break leaves i un-incremented (:20)
-                marching = false;
-                i_final = trips;
-            } else {
-                t = t + d;
-                p = V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
-                       fmaf_(t, dir.z, P.origin.z)};
-                marching = more && (t < P.max_distance);
-                i_final = trips + 1;
-            }
-        }
+        // The SDF is evaluated for every lane (stopped lanes hold a valid old position, their
+        // result is discarded): no divergent region around the expensive part, the state update
+        // is a handful of selects.
+        const float d = scene_sdf<GROUP, PRIM>(P, p);
+        const bool h = marching && (d < P.epsilon);
+        const bool go = marching && !h;
+        hit = hit || h;  // break leaves i un-incremented (:20)
+        if (__builtin_expect(P.is_heatmap != 0u, 0))
+            i_final = h ? trips : (go ? trips + 1 : i_final);
+        const float tn = t + d;
+        t = go ? tn : t;
+        p = V3{go ? fmaf_(tn, dir.x, P.origin.x) : p.x, go ? fmaf_(tn, dir.y, P.origin.y) : p.y,
+               go ? fmaf_(tn, dir.z, P.origin.z) : p.z};
+        marching = go && more && (tn < P.max_distance);
         ++trips;
     }
     __builtin_amdgcn_s_setprio(0);
