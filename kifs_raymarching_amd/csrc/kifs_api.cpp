@@ -33,7 +33,15 @@ static_assert(offsetof(KifsOptionsUniform, constant) == 64, "constant at 64");
 // device; a context alternates between very few geometries (full frame, its band).
 struct TileTable {
     int width = 0, height = 0, y0 = 0, y1 = 0;
-    uint32_t* d_order = nullptr;
+    uint32_t* d_order = nullptr;      // order used by the next launch
+    uint32_t* d_order_alt = nullptr;  // the other half of the double buffer (the sort's target)
+    uint32_t* d_cost[2] = {nullptr, nullptr};  // per-tile cost, written by launch k into [k & 1]
+    hipEvent_t rendered[2] = {nullptr, nullptr};  // recorded after launch k into [k & 1]
+    hipEvent_t sorted = nullptr;      // recorded after the sort that fills d_order_alt
+    uint64_t launches = 0;            // consecutive feedback launches made with this table
+    hipStream_t last_stream = nullptr;  // stream of the latest of them
+    bool sort_pending = false;        // d_order_alt holds (or will hold) a fresh order
+    bool feedback = true;             // reorder from costs (off once the caller pins an order)
     uint32_t count = 0;
     uint64_t last_use = 0;
 };
@@ -44,6 +52,7 @@ struct kifs_ctx {
     TileTable tables[MAX_TILE_TABLES];
     uint64_t use_clock = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;  // tile-order sorts run here, beside the renders
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float* d_srgb = nullptr;       // 256 thresholds
     uint8_t* d_scratch = nullptr;  // frame staging for host destinations
@@ -167,6 +176,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->srgb_table = c->d_srgb;
     P->tile_order = nullptr;
     P->tile_count = 0;
+    P->tile_cost = nullptr;
     P->counters = c->d_counters;
     P->workgroups_per_cu = 0;
     return KIFS_OK;
@@ -182,10 +192,29 @@ bool is_device_pointer(const void* p) {
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+static void free_table(TileTable& t) {
+    if (t.d_order) (void)hipFree(t.d_order);
+    if (t.d_order_alt) (void)hipFree(t.d_order_alt);
+    for (int i = 0; i < 2; ++i) {
+        if (t.d_cost[i]) (void)hipFree(t.d_cost[i]);
+        if (t.rendered[i]) (void)hipEventDestroy(t.rendered[i]);
+    }
+    if (t.sorted) (void)hipEventDestroy(t.sorted);
+    t = TileTable();
+}
+
+static bool tile_feedback_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("KIFS_TILE_FEEDBACK");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // Order in which workgroups take tiles: nearest to the frame centre first (squared
 // distance of the tile centre, ties by row then column), so the long rays start first.
 // Tiles are TILE_W x TILE_H pixels; rows are counted from the top of the band.
-const TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
+TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
     TileTable* slot = nullptr;
     for (auto& t : c->tables) {
         if (t.d_order && t.width == width && t.height == height && t.y0 == y0 && t.y1 == y1) {
@@ -215,16 +244,20 @@ const TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) 
     // the slot being replaced may still be read by an enqueued launch: drain first
     if (slot->d_order) {
         hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize(before tile table eviction)");
-        hip_ok(hipFree(slot->d_order), "hipFree(tile order)");
-        slot->d_order = nullptr;
+        free_table(*slot);
     }
-    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&slot->d_order), order.size() * sizeof(uint32_t)),
-                "hipMalloc(tile order)"))
-        return nullptr;
-    if (!hip_ok(hipMemcpy(slot->d_order, order.data(), order.size() * sizeof(uint32_t),
-                          hipMemcpyHostToDevice), "hipMemcpy(tile order)")) {
-        (void)hipFree(slot->d_order);
-        slot->d_order = nullptr;
+    const size_t bytes = order.size() * sizeof(uint32_t);
+    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&slot->d_order), bytes), "hipMalloc(tile order)") ||
+        !hip_ok(hipMalloc(reinterpret_cast<void**>(&slot->d_order_alt), bytes), "hipMalloc(tile order 2)") ||
+        !hip_ok(hipMalloc(reinterpret_cast<void**>(&slot->d_cost[0]), bytes), "hipMalloc(tile cost)") ||
+        !hip_ok(hipMalloc(reinterpret_cast<void**>(&slot->d_cost[1]), bytes), "hipMalloc(tile cost 2)") ||
+        !hip_ok(hipEventCreateWithFlags(&slot->rendered[0], hipEventDisableTiming), "hipEventCreate") ||
+        !hip_ok(hipEventCreateWithFlags(&slot->rendered[1], hipEventDisableTiming), "hipEventCreate") ||
+        !hip_ok(hipEventCreateWithFlags(&slot->sorted, hipEventDisableTiming), "hipEventCreate") ||
+        !hip_ok(hipMemcpy(slot->d_order, order.data(), bytes, hipMemcpyHostToDevice), "hipMemcpy(tile order)") ||
+        !hip_ok(hipMemset(slot->d_cost[0], 0, bytes), "hipMemset(tile cost)") ||
+        !hip_ok(hipMemset(slot->d_cost[1], 0, bytes), "hipMemset(tile cost)")) {
+        free_table(*slot);
         return nullptr;
     }
     slot->width = width; slot->height = height; slot->y0 = y0; slot->y1 = y1;
@@ -281,14 +314,57 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
     P.pitch_words = uint32_t(pitch >> 2);
     P.out = reinterpret_cast<uint32_t*>(dev_out);
     if (y1 == y0) return KIFS_OK;
-    const TileTable* tt = tile_table(c, P.width, h, y0, y1);
+    TileTable* tt = tile_table(c, P.width, h, y0, y1);
     if (!tt) return KIFS_ERR_RUNTIME;
+    // Temporal feedback on the tile order.  Every launch leaves a cost per tile (the run time of
+    // the tile's slowest wave); a one-workgroup counting sort on the context's side stream turns
+    // the costs of launch k-1 into the order of launch k+1 while launch k is running, so the
+    // sort is off the critical path.  The longest rays sit at the fractal's silhouette, which
+    // no static order knows; with them first the frame ends when they do.  Tables:
+    //   d_order      read by launch k          d_order_alt   written by the sort (was read by k-1)
+    //   d_cost[k&1]  written by launch k       d_cost[~k&1]  read by the sort (written by k-1)
+    // Events order everything whichever streams the caller uses.  Off for the KIFS pipelines and
+    // small frames, where it does not pay for itself.
+    const bool use_feedback = tt->feedback && tile_feedback_enabled() &&
+                              c->options.fractal_group_id != uint32_t(kifs::GROUP_KIFS) && tt->count >= 2048;
+    if (use_feedback && tt->sort_pending) {  // adopt the order the side stream prepared
+        if (!hip_ok(hipStreamWaitEvent(stream, tt->sorted, 0), "wait(sorted)")) return KIFS_ERR_RUNTIME;
+        std::swap(tt->d_order, tt->d_order_alt);
+        tt->sort_pending = false;
+    }
+    const uint64_t k = tt->launches;
     P.tile_order = tt->d_order;
     P.tile_count = tt->count;
+    P.tile_cost = use_feedback ? tt->d_cost[k & 1] : nullptr;
     P.workgroups_per_cu = residency_for(P, c->options.fractal_group_id, h, tt->count);
+    if (use_feedback && k >= 2 && stream != tt->last_stream &&
+        !hip_ok(hipStreamWaitEvent(stream, tt->rendered[k & 1], 0), "wait(render k-2)"))
+        return KIFS_ERR_RUNTIME;  // launch k-2 wrote the same cost buffer; only matters across streams
     hipError_t e = kifs::launch_render(P, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
-    return hip_ok(e, "render_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;
+    if (!hip_ok(e, "render_kernel launch")) return KIFS_ERR_RUNTIME;
+    if (!use_feedback) {  // no bookkeeping, no events: nothing depends on this launch
+        tt->launches = 0;
+        tt->sort_pending = false;
+        return KIFS_OK;
+    }
+    if (!hip_ok(hipEventRecord(tt->rendered[k & 1], stream), "record(render)")) return KIFS_ERR_RUNTIME;
+    tt->launches = k + 1;
+    tt->last_stream = stream;
+    if (k >= 1) {
+        // sort the costs of launch k-1 into d_order_alt (the order launch k-1 used, now idle)
+        if (!c->side_stream &&
+            !hip_ok(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "side stream"))
+            return KIFS_ERR_RUNTIME;
+        const uint32_t tiles_x = uint32_t((P.width + kifs::TILE_W - 1) / kifs::TILE_W);
+        if (!hip_ok(hipStreamWaitEvent(c->side_stream, tt->rendered[(k - 1) & 1], 0), "wait(render k-1)") ||
+            !hip_ok(kifs::launch_tile_order(tt->d_cost[(k - 1) & 1], tt->d_order_alt, tt->count, tiles_x,
+                                            c->side_stream), "tile_order_kernel launch") ||
+            !hip_ok(hipEventRecord(tt->sorted, c->side_stream), "record(sorted)"))
+            return KIFS_ERR_RUNTIME;
+        tt->sort_pending = true;
+    }
+    return KIFS_OK;
 }
 
 }  // namespace
@@ -346,8 +422,12 @@ void kifs_destroy(kifs_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+    }
     for (auto& t : c->tables)
-        if (t.d_order) (void)hipFree(t.d_order);
+        if (t.d_order) free_table(t);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_srgb) (void)hipFree(c->d_srgb);
@@ -500,9 +580,10 @@ int kifs_debug_set_tile_order(kifs_ctx* c, const uint32_t* order, size_t count) 
     int w, h;
     if (!c->have_screen || frame_dims(c, &w, &h) != KIFS_OK) return KIFS_ERR_UNCONFIGURED;
     DeviceGuard g(c->device);
-    const TileTable* tt = tile_table(c, w, h, 0, h);
+    TileTable* tt = tile_table(c, w, h, 0, h);
     if (!tt) return KIFS_ERR_RUNTIME;
     if (count != tt->count) return KIFS_ERR_BAD_ARG;
+    tt->feedback = false;  // a pinned order stays until the table is rebuilt
     std::vector<char> seen(count, 0);  // must be a permutation of the frame's tiles
     const uint32_t tx = uint32_t((w + kifs::TILE_W - 1) / kifs::TILE_W);
     const uint32_t ty = uint32_t((h + kifs::TILE_H - 1) / kifs::TILE_H);

@@ -33,6 +33,7 @@ template <int GROUP, int PRIM>
 __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
     __shared__ float s_srgb[256];
     __shared__ uint32_t s_tile[TILE_H][TILE_W];
+    __shared__ int s_steps[BLOCK / 64];
 
     const int tid = threadIdx.x;
     const bool srgb = (P.encode == 1);
@@ -50,12 +51,30 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
     const bool valid = (x < P.width) && (y < P.y1);
 
     V3 colour{0.0f, 0.0f, 0.0f};
+    int steps = 0;  // wave-uniform: march steps this wave needed
+    const bool feedback = P.tile_cost != nullptr;  // wave-uniform
+    const unsigned long long wave_start = feedback ? __builtin_amdgcn_s_memtime() : 0ull;
     if (__ballot(valid) != 0ull) {
         V3 dir = ray_direction(P, x, y);
-        colour = raymarch<GROUP, PRIM>(P, dir, valid);
+        colour = raymarch<GROUP, PRIM>(P, dir, valid, steps);
     }
+    // cost of this wave for the next frame's tile order: its run time in units of 1024 cycles,
+    // minus a floor that maps culled / instant waves to 0 (march steps alone are too coarse:
+    // hundreds of tiles tie at max_iterations)
+    if (feedback) {
+        const unsigned long long wave_cycles = __builtin_amdgcn_s_memtime() - wave_start;
+        if (lane == 0)
+            s_steps[wave] = int(min(wave_cycles > 4096ull ? (wave_cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
+    }
+    (void)steps;
 
-    __syncthreads();  // s_srgb visible
+    __syncthreads();  // s_srgb and s_steps visible
+    // cost feedback for the next frame's tile order: the tile's slowest wave
+    if (tid == 0 && feedback) {
+        const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
+        const int m = max(max(s_steps[0], s_steps[1]), max(s_steps[2], s_steps[3]));
+        P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)] = uint32_t(m);
+    }
     uint32_t r, g, b;
     if (srgb) {
         r = srgb8(colour.x, s_srgb);
@@ -135,6 +154,68 @@ hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitiv
         }
     default: return hipErrorInvalidValue;
     }
+}
+
+// ---- tile order from the previous frame's costs -----------------------------------------
+// One 1024-thread workgroup: histogram of clamped costs (bin 0 = heaviest), exclusive scan,
+// scatter.  Whatever the cost values are, the result is a permutation of the tile ids, so a
+// stale or garbage cost table can only cost speed, never pixels.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost,
+                                                          uint32_t* __restrict__ order, uint32_t n,
+                                                          uint32_t tiles_x) {
+    constexpr uint32_t BINS = 1024, LAST = BINS - 1;  // bin 0 = heaviest, LAST = cost 0
+    __shared__ uint32_t bins[BINS];
+    __shared__ uint32_t wave_total[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    bins[tid] = 0;
+    __syncthreads();
+    const uint32_t rounds = (n + 1023u) / 1024u;  // wave-uniform trip count (ballots inside)
+    // After the culls almost every tile has cost 0: that class is counted with one atomic per
+    // wave (ballot + popcount) instead of 64 atomics on the same LDS word.
+    for (uint32_t k = 0; k < rounds; ++k) {
+        const uint32_t i = k * 1024u + tid;
+        const bool live = i < n;
+        const uint32_t bin = live ? LAST - min(cost[i], LAST) : 0u;
+        const bool zero = live && bin == LAST;
+        const unsigned long long zmask = __builtin_amdgcn_ballot_w64(zero);
+        if (lane == 0 && zmask) atomicAdd(&bins[LAST], uint32_t(__builtin_popcountll(zmask)));
+        if (live && !zero) atomicAdd(&bins[bin], 1u);
+    }
+    __syncthreads();
+    const uint32_t mine = bins[tid];
+    uint32_t incl = mine;  // inclusive scan inside the wave
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        uint32_t up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63u) wave_total[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < w; ++k) base += wave_total[k];
+    bins[tid] = base + incl - mine;  // exclusive prefix = first slot of this bin
+    __syncthreads();
+    for (uint32_t k = 0; k < rounds; ++k) {
+        const uint32_t i = k * 1024u + tid;
+        const bool live = i < n;
+        const uint32_t bin = live ? LAST - min(cost[i], LAST) : 0u;
+        const bool zero = live && bin == LAST;
+        const unsigned long long zmask = __builtin_amdgcn_ballot_w64(zero);
+        uint32_t zbase = 0;
+        if (lane == 0 && zmask) zbase = atomicAdd(&bins[LAST], uint32_t(__builtin_popcountll(zmask)));
+        zbase = __shfl(zbase, 0);
+        uint32_t pos;
+        if (zero) pos = zbase + uint32_t(__builtin_popcountll(zmask & ((1ull << lane) - 1ull)));
+        else if (live) pos = atomicAdd(&bins[bin], 1u);
+        if (live) order[pos] = (i % tiles_x) | ((i / tiles_x) << 16);
+    }
+}
+
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t tile_count,
+                             uint32_t tiles_x, hipStream_t stream) {
+    if (tile_count == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, tile_count, tiles_x);
+    return hipGetLastError();
 }
 
 // ---- point evaluation (parity tests) --------------------------------------------------

@@ -42,6 +42,7 @@ struct FrameParams {
     const float* srgb_table;            // 256 thresholds, device memory
     const uint32_t* tile_order;         // workgroup b renders tile (order[b] & 0xffff, order[b] >> 16)
     uint32_t tile_count;
+    uint32_t* tile_cost;                // per tile (row-major tile index): march steps of its slowest wave
     // Optional device counters (nullptr in normal operation): [0] wave-steps taken in the
     // hand-written long-ray loop, [1] wave-steps taken on the general path, [2] entries into
     // the long-ray loop, [3] waves.  Enabled by kifs_debug_counters().

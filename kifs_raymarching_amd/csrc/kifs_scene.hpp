@@ -631,7 +631,7 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 // run through julia_interior), every marching lane outside (background: a sqrt and a
 // subtract), or mixed.  That keeps taken branches -- the expensive thing for a lone wave --
 // to the loop's back edge.
-KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid) {
+KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps) {
     float t = 0.0f;
     V3 p = P.origin;
     bool hit = false;
@@ -699,6 +699,7 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid) {
         ++general_steps;
     }
     __builtin_amdgcn_s_setprio(0);
+    steps = trips;
     if (__builtin_expect(stamp, 0)) {
         // per-wave record (no atomics: they would serialise the waves being measured):
         // total ticks, ticks in the long-ray loop, long-ray steps | entries << 32, general steps
@@ -732,8 +733,8 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid) {
 // marching (wave-level early ray termination); normals are evaluated once, after
 // the loop, for the lanes that hit, so that divergent work is bunched together.
 template <int GROUP, int PRIM>
-KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
-    if constexpr (GROUP == GROUP_JULIA) return raymarch_julia(P, dir, valid);
+KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
+    if constexpr (GROUP == GROUP_JULIA) return raymarch_julia(P, dir, valid, steps);
     float t = 0.0f;
     V3 p = P.origin;
     bool hit = false;
@@ -763,6 +764,7 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid) {
         ++trips;
     }
     __builtin_amdgcn_s_setprio(0);
+    steps = trips;
     V3 colour = P.background_color;
     if (hit) {
         V3 n = scene_normal<GROUP, PRIM>(P, p);
