@@ -160,9 +160,28 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->normal_iters = c->normal_iters;
     P->fold_iters = c->fold_iters;
     P->bound_n2 = squared_threshold(2.0f + o.epsilon);
-    {   // culls need a sane sphere radius R = 2 + epsilon > 0 and a positive epsilon test
-        const float R = 2.0f + o.epsilon;
-        P->cull_n2 = (R > 0.5f && R < 1.0e6f && o.epsilon >= 0.0f) ? 1.1f * R * R : 0.0f;
+    {   // Bounding-sphere culls: every scene's estimate obeys d(p) >= |p| - B, so outside radius
+        // R = B + epsilon (plus margin) `d < epsilon` cannot happen.  B per scene:
+        //   Julia / gen-Julia: 2 (the patch of julia.wgsl:8-9)      sphere r=1: 1
+        //   cylinder (r=1, half-height 2): sqrt(5)                   box (1,1,1): sqrt(3)
+        //   torus (1, 0.3): 1.3        bunny: 1 (patch |p| - 0.8 outside the unit ball)
+        //   Sierpinski: 2 -- folds are isometries and pos <- 2 pos - 1 gives r_k >= 2^k r_0 -
+        //   sqrt(3)(2^k - 1), hence (r_k - 2)/2^k >= r_0 - 2 for every number of folds.
+        float B = 2.0f;
+        if (o.fractal_group_id == uint32_t(kifs::GROUP_KIFS)) {
+            switch (o.primitive_id) {
+            case kifs::PRIM_SPHERE: B = 1.0f; break;
+            case kifs::PRIM_CYLINDER: B = 2.2360680f; break;
+            case kifs::PRIM_BOX: B = 1.7320508f; break;
+            case kifs::PRIM_TORUS: B = 1.3f; break;
+            case kifs::PRIM_SIERPINSKI: B = 2.0f; break;
+            case kifs::PRIM_BUNNY: B = 1.0f; break;
+            default: B = -1.0f; break;  // unknown id: the SDF is the constant 1, no bound
+            }
+        }
+        const float R = B + o.epsilon;
+        const bool sane = B > 0.0f && R > 0.5f && R < 1.0e6f && o.epsilon >= 0.0f;
+        P->cull_n2 = sane ? 1.1f * R * R : 0.0f;
     }
     P->orbit_blocks = c->sdf_iters / 6;
     P->orbit_rem = c->sdf_iters % 6;
@@ -275,7 +294,7 @@ TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
 // CU); if they are many (4096^2, or a camera close to the fractal) the frame is bound by their
 // aggregate instruction throughput and full residency wins (4096^2: 0.70 ms vs 1.95 ms capped).
 int residency_for(const kifs::FrameParams& P, uint32_t group, int frame_height, uint32_t tile_count) {
-    if (group == kifs::GROUP_KIFS || P.cull_n2 <= 0.0f || P.is_heatmap) return 0;
+    if (group != kifs::GROUP_JULIA || P.cull_n2 <= 0.0f || P.is_heatmap) return 0;
     const double R2 = double(P.cull_n2) / 1.1;  // (2 + epsilon)^2
     const double d2 = double(P.origin.x) * P.origin.x + double(P.origin.y) * P.origin.y +
                       double(P.origin.z) * P.origin.z;

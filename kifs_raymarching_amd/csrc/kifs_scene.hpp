@@ -743,10 +743,26 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
     int trips = 0;
     int i_final = 0;
     bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
+    // Bounding-sphere culls (see raymarch_julia and fill_params): every scene's estimate obeys
+    // d(p) >= |p| - B, so a ray that never comes within R = B + epsilon of the origin, or a lane
+    // outside R and moving away, can never satisfy `d < epsilon`.  Not in heatmap mode.
+    const bool cull = (P.is_heatmap == 0u) && (P.cull_n2 > 0.0f);  // wave-uniform
+    if (cull) {
+        const float oo = dot(P.origin, P.origin);
+        const float b = -dot(P.origin, dir);
+        const float c2 = fmaf_(-b, b, oo);
+        const bool never_inside = (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
+        marching = marching && !never_inside;
+    }
     while (__builtin_amdgcn_ballot_w64(marching) != 0ull) {
         // a ray still marching after 32 steps is on the frame's critical path: issue it first
         if (trips == 32) __builtin_amdgcn_s_setprio(3);
         const bool more = (trips + 1) < P.max_iterations;  // scalar
+        if (cull) {  // early ray termination for lanes that are leaving for good
+            const bool leaving = (dot(p, p) > P.cull_n2) && (dot(p, dir) > 0.0f);
+            marching = marching && !leaving;
+            if (__builtin_amdgcn_ballot_w64(marching) == 0ull) break;
+        }
         // The SDF is evaluated for every lane (stopped lanes hold a valid old position, their
         // result is discarded): no divergent region around the expensive part, the state update
         // is a handful of selects.
