@@ -140,6 +140,8 @@ def main():
     W, H = w.screen.width, w.screen.height
     gs = K.GraphicState(local_rank, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
     gs.set_iters(*w.iters)
+    if w.extensions:
+        gs.set_extensions(**w.extensions)
     # Everything (kernel launches, events, the RCCL gather's stream dependencies) runs on
     # one dedicated non-default stream, made current for the whole benchmark.
     stream = torch.cuda.Stream(device=device)

@@ -123,6 +123,26 @@ int kifs_set_options(kifs_ctx* ctx, const KifsOptionsUniform* options); /* graph
  * Those are the defaults; BASELINE configs override them.  All must be >= 0. */
 int kifs_set_iters(kifs_ctx* ctx, int sdf_iters, int normal_iters, int fold_iters);
 
+/* ---- extension: soft shadows ---------------------------------------------------------
+ * NOT part of the reference (its whole shading model is entry.wgsl:6-29); BASELINE config 5
+ * names "soft-shadow secondary rays", so it exists as an explicit opt-in whose semantics this
+ * library defines.  With soft_shadow != 0, every hit pixel marches a secondary ray from
+ * p + 2*epsilon*n towards L = normalize((1,1,1)) (the direction of the reference's light
+ * vector, entry.wgsl:17):
+ *     res = 1; t = shadow_t0
+ *     up to shadow_steps times: h = scene_SDF(start + t*L); if h < epsilon -> res = 0, stop;
+ *                               res = min(res, shadow_k*h/t); t += h; stop if t > shadow_max_t
+ * and the direct term is attenuated: diffuse = 0.1 + 0.9 * clamp(n.(1,1,1), 0, 1) * res.
+ * All zero (the default) is the reference's behaviour exactly. */
+typedef struct KifsExtensions {
+    uint32_t soft_shadow;
+    int32_t shadow_steps;
+    float shadow_k;
+    float shadow_t0;
+    float shadow_max_t;
+} KifsExtensions;
+int kifs_set_extensions(kifs_ctx* ctx, const KifsExtensions* ext);
+
 /* ---- render ---------------------------------------------------------------
  * Replaces GraphicState::render (graphics.rs:310-325): pipeline chosen by
  * options.fractal_group_id, one kernel launch instead of draw(0..3, 0..2).
@@ -162,6 +182,7 @@ int kifs_multi_set_screen(kifs_multi* m, const KifsScreenUniform* screen);
 int kifs_multi_set_camera(kifs_multi* m, const KifsCameraUniform* camera);
 int kifs_multi_set_options(kifs_multi* m, const KifsOptionsUniform* options);
 int kifs_multi_set_iters(kifs_multi* m, int sdf_iters, int normal_iters, int fold_iters);
+int kifs_multi_set_extensions(kifs_multi* m, const KifsExtensions* ext);
 /* `out_rgba8`: host memory or device memory of the root device; full frame, `pitch_bytes`
  * per row.  Returns when the frame is complete. */
 int kifs_multi_render(kifs_multi* m, uint8_t* out_rgba8, size_t pitch_bytes, int encode);

@@ -36,6 +36,11 @@ class OptionsUniform(C.Structure):  # data.rs:33-49
                 ("constant", C.c_float * 4)]
 
 
+class ExtensionsC(C.Structure):  # KifsExtensions
+    _fields_ = [("soft_shadow", C.c_uint32), ("shadow_steps", C.c_int32), ("shadow_k", C.c_float),
+                ("shadow_t0", C.c_float), ("shadow_max_t", C.c_float)]
+
+
 class GuiDataC(C.Structure):  # KifsGuiData
     _fields_ = [("max_iterations", C.c_uint32), ("max_distance", C.c_float),
                 ("epsilon", C.c_float), ("fractal_color", C.c_uint8 * 3),
@@ -65,6 +70,8 @@ SIGNATURES = {
     "kifs_set_camera": (C.c_int, [_ctx, _P(CameraUniform)]),
     "kifs_set_options": (C.c_int, [_ctx, _P(OptionsUniform)]),
     "kifs_set_iters": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
+    "kifs_set_extensions": (C.c_int, [_ctx, _P(ExtensionsC)]),
+    "kifs_multi_set_extensions": (C.c_int, [_ctx, _P(ExtensionsC)]),
     "kifs_render": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "kifs_render_async": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                     C.c_int]),

@@ -22,6 +22,7 @@ class Workload:
     camera: CameraData = field(default_factory=CameraData)
     frames: int = 1
     gpus: int = 1
+    extensions: dict = None  # keyword arguments of GraphicState.set_extensions (soft shadows)
 
     @property
     def pixels(self):
@@ -53,6 +54,12 @@ WORKLOADS = {
                                          ScreenData(7680, 4320), _sierpinski(256), (100, 10, 16),
                                          camera=CameraData(origin_distance=3.0, theta=0.3),
                                          frames=120, gpus=8),
+    # configs[4] with the soft-shadow extension switched on (no reference counterpart)
+    "cfg5_sierpinski_8k_orbit_shadows": Workload(
+        "7680x4320 KIFS Sierpinski orbit, 16 folds, 256 steps, soft-shadow secondary rays",
+        ScreenData(7680, 4320), _sierpinski(256), (100, 10, 16),
+        camera=CameraData(origin_distance=3.0, theta=0.3), frames=120, gpus=8,
+        extensions=dict(soft_shadow=True, shadow_steps=64, shadow_k=8.0, shadow_t0=0.02, shadow_max_t=10.0)),
     # the reference exactly as shipped: GUI-default constant, hard-coded iteration counts
     "ref_julia_1080p": Workload("1920x1080 Julia, reference constants (100/10), GUI default c",
                                 ScreenData(1920, 1080),

@@ -62,6 +62,7 @@ struct kifs_ctx {
     KifsOptionsUniform options{};
     bool have_screen = false, have_camera = false, have_options = false;
     int sdf_iters = 100, normal_iters = 10, fold_iters = 10;  // julia.wgsl:2-3, kifs.wgsl:72
+    KifsExtensions ext{};  // all zero: the reference's behaviour
     double last_ms = -1.0;
     bool timing_pending = false;
     unsigned long long* d_counters = nullptr;  // diagnostics buffer, see FrameParams
@@ -159,6 +160,11 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->sdf_iters = c->sdf_iters;
     P->normal_iters = c->normal_iters;
     P->fold_iters = c->fold_iters;
+    P->soft_shadow = c->ext.soft_shadow;
+    P->shadow_steps = c->ext.shadow_steps;
+    P->shadow_k = c->ext.shadow_k;
+    P->shadow_t0 = c->ext.shadow_t0;
+    P->shadow_max_t = c->ext.shadow_max_t;
     P->bound_n2 = squared_threshold(2.0f + o.epsilon);
     {   // Bounding-sphere culls: every scene's estimate obeys d(p) >= |p| - B, so outside radius
         // R = B + epsilon (plus margin) `d < epsilon` cannot happen.  B per scene:
@@ -491,6 +497,13 @@ int kifs_set_iters(kifs_ctx* c, int sdf_iters, int normal_iters, int fold_iters)
     return KIFS_OK;
 }
 
+int kifs_set_extensions(kifs_ctx* c, const KifsExtensions* ext) {
+    if (!c || !ext) return KIFS_ERR_BAD_ARG;
+    if (ext->soft_shadow && ext->shadow_steps < 0) return KIFS_ERR_BAD_ARG;
+    c->ext = *ext;
+    return KIFS_OK;
+}
+
 int kifs_band_range(int height, int rank, int world, int* y0, int* y1) {
     if (height < 0 || world <= 0 || rank < 0 || rank >= world || !y0 || !y1)
         return KIFS_ERR_BAD_ARG;
@@ -775,6 +788,7 @@ int kifs_multi_set_screen(kifs_multi* m, const KifsScreenUniform* s) { KIFS_MULT
 int kifs_multi_set_camera(kifs_multi* m, const KifsCameraUniform* cam) { KIFS_MULTI_FORWARD(kifs_set_camera(c, cam)) }
 int kifs_multi_set_options(kifs_multi* m, const KifsOptionsUniform* o) { KIFS_MULTI_FORWARD(kifs_set_options(c, o)) }
 int kifs_multi_set_iters(kifs_multi* m, int a, int b, int f) { KIFS_MULTI_FORWARD(kifs_set_iters(c, a, b, f)) }
+int kifs_multi_set_extensions(kifs_multi* m, const KifsExtensions* e) { KIFS_MULTI_FORWARD(kifs_set_extensions(c, e)) }
 
 int kifs_multi_band(kifs_multi* m, int i, int* device, int* y0, int* y1) {
     if (!m || i < 0 || size_t(i) >= m->ctx.size() || !y0 || !y1) return KIFS_ERR_BAD_ARG;

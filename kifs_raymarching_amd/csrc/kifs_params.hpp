@@ -35,6 +35,10 @@ struct FrameParams {
     // Smallest f32 v with sqrt(v) >= max_distance: `length(pos) < max_distance` (kifs.wgsl:72)
     // is exactly `dot(pos,pos) < fold_n2_stop`.
     float fold_n2_stop;
+    // extension (include/kifs_hip.h KifsExtensions); soft_shadow == 0: the reference's shading
+    uint32_t soft_shadow;
+    int shadow_steps;
+    float shadow_k, shadow_t0, shadow_max_t;
     int width, y0, y1;                  // frame width, row band [y0, y1)
     int encode;                         // KifsEncode
     uint32_t pitch_words;               // output row pitch in 32-bit words

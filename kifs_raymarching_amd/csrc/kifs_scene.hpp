@@ -391,6 +391,38 @@ KIFS_DEV V3 ray_direction(const FrameParams& P, int x, int y) {
     return normalize(d);
 }
 
+// ---- extension: soft shadows (not in the reference; see KifsExtensions) ------------------
+// Secondary march from the hit point towards the light, operation for operation as
+// specified in include/kifs_hip.h (KifsExtensions).  `lanes_hit` selects the lanes that take part; the loop leaves
+// when none of them is still marching.
+template <int GROUP, int PRIM>
+KIFS_DEV float scene_sdf(const FrameParams& P, V3 p);
+
+template <int GROUP, int PRIM>
+KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit) {
+    const V3 L = normalize(V3{1.0f, 1.0f, 1.0f});
+    const float off = 2.0f * P.epsilon;
+    const V3 start{fmaf_(off, n.x, p.x), fmaf_(off, n.y, p.y), fmaf_(off, n.z, p.z)};
+    float res = 1.0f;
+    float t = P.shadow_t0;
+    bool marching = lanes_hit && (0 < P.shadow_steps);
+    for (int j = 0; __builtin_amdgcn_ballot_w64(marching) != 0ull; ++j) {
+        if (marching) {
+            const V3 q{fmaf_(t, L.x, start.x), fmaf_(t, L.y, start.y), fmaf_(t, L.z, start.z)};
+            const float h = scene_sdf<GROUP, PRIM>(P, q);
+            if (h < P.epsilon) {
+                res = 0.0f;
+                marching = false;
+            } else {
+                res = min_(res, (P.shadow_k * h) / t);
+                t = t + h;
+                marching = !(t > P.shadow_max_t) && (j + 1 < P.shadow_steps);
+            }
+        }
+    }
+    return res;
+}
+
 // ---- the long-ray loop: every live lane inside the bounding sphere -------------------------
 // The rays that decide a frame's run time skim the fractal for hundreds of steps, deep inside
 // the bounding sphere, alone on their SIMD.  For that state -- no live lane outside the sphere,
@@ -716,7 +748,9 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
     if (hit) {
         V3 n = julia_normal(P, p);
         float ndl = (n.x + n.y) + n.z;
-        float diffuse = fmaf_(0.9f, clamp_(ndl, 0.0f, 1.0f), 0.1f);
+        float lit = clamp_(ndl, 0.0f, 1.0f);
+        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow<GROUP_JULIA, 0>(P, p, n, true);
+        float diffuse = fmaf_(0.9f, lit, 0.1f);
         colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
                     diffuse * P.fractal_color.z};
     }
@@ -785,7 +819,9 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
     if (hit) {
         V3 n = scene_normal<GROUP, PRIM>(P, p);
         float ndl = (n.x + n.y) + n.z;  // dot(n, (1,1,1)): the light is not normalised (:17)
-        float diffuse = fmaf_(0.9f, clamp_(ndl, 0.0f, 1.0f), 0.1f);
+        float lit = clamp_(ndl, 0.0f, 1.0f);
+        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow<GROUP, PRIM>(P, p, n, true);
+        float diffuse = fmaf_(0.9f, lit, 0.1f);
         colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
                     diffuse * P.fractal_color.z};
     }

@@ -18,7 +18,7 @@ from enum import IntEnum
 import numpy as np
 
 from . import _lib
-from ._lib import (CameraDataC, CameraUniform, GuiDataC, KifsError, OptionsUniform,
+from ._lib import (CameraDataC, CameraUniform, ExtensionsC, GuiDataC, KifsError, OptionsUniform,
                    ScreenUniform, check, lib)
 
 ENCODE_UNORM = _lib.ENCODE_UNORM
@@ -242,6 +242,12 @@ class GraphicState:
     def set_iters(self, sdf_iters=100, normal_iters=10, fold_iters=10):
         check(lib.kifs_set_iters(self._ctx, sdf_iters, normal_iters, fold_iters), "set_iters")
         self.iters = (sdf_iters, normal_iters, fold_iters)
+
+    def set_extensions(self, soft_shadow=False, shadow_steps=64, shadow_k=8.0, shadow_t0=0.02,
+                       shadow_max_t=10.0):
+        """Opt-in soft shadows (an extension; absent from the reference).  Off = reference shading."""
+        e = ExtensionsC(1 if soft_shadow else 0, shadow_steps, shadow_k, shadow_t0, shadow_max_t)
+        check(lib.kifs_set_extensions(self._ctx, C.byref(e)), "set_extensions")
 
     # -- render (graphics.rs:310-325) -----------------------------------------------------
     def render(self, out=None, y0: int = 0, y1: int = None, encode: int = ENCODE_SRGB,

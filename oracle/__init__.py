@@ -38,6 +38,11 @@ class Iters(C.Structure):
                 ("fold_iters", C.c_int32)]
 
 
+class Ext(C.Structure):
+    _fields_ = [("soft_shadow", C.c_uint32), ("shadow_steps", C.c_int32), ("shadow_k", C.c_float),
+                ("shadow_t0", C.c_float), ("shadow_max_t", C.c_float)]
+
+
 class Stats(C.Structure):
     _fields_ = [("pixels", C.c_uint64), ("march_steps", C.c_uint64),
                 ("inner_iters", C.c_uint64), ("hits", C.c_uint64),
@@ -84,6 +89,8 @@ def lib():
     sigs = {
         "kor_render": (C.c_int, [P(Screen), P(Camera), P(Options), P(Iters), i32, i32, i32, u8p,
                                  C.c_size_t, i32]),
+        "kor_render_ext": (C.c_int, [P(Screen), P(Camera), P(Options), P(Iters), P(Ext), i32, i32, i32,
+                                     u8p, C.c_size_t, i32]),
         "kor_render_stats": (C.c_int, [P(Screen), P(Camera), P(Options), P(Iters), i32, i32, i32,
                                        u8p, C.c_size_t, P(Stats), P(C.c_uint16)]),
         "kor_shade_pixel": (C.c_int, [P(Screen), P(Camera), P(Options), P(Iters), i32, i32,
@@ -165,14 +172,15 @@ def iters(sdf_iters=100, normal_iters=10, fold_iters=10):
     return Iters(sdf_iters, normal_iters, fold_iters)
 
 
-def render(screen, camera, options, it=None, encode=1, y0=0, y1=None, nthreads=0):
-    """RGBA8 rows [y0,y1) as a (rows, W, 4) uint8 array."""
+def render(screen, camera, options, it=None, encode=1, y0=0, y1=None, nthreads=0, ext=None):
+    """RGBA8 rows [y0,y1) as a (rows, W, 4) uint8 array.  `ext`: Ext (soft-shadow extension)."""
     w, h = int(screen.width), int(screen.height)
     y1 = h if y1 is None else y1
     it = it or iters()
     out = np.zeros((max(y1 - y0, 0), w, 4), dtype=np.uint8)
-    rc = lib().kor_render(C.byref(screen), C.byref(camera), C.byref(options), C.byref(it), encode,
-                          y0, y1, out.ctypes.data_as(C.POINTER(C.c_uint8)), w * 4, nthreads)
+    rc = lib().kor_render_ext(C.byref(screen), C.byref(camera), C.byref(options), C.byref(it),
+                              C.byref(ext) if ext is not None else None, encode,
+                              y0, y1, out.ctypes.data_as(C.POINTER(C.c_uint8)), w * 4, nthreads)
     if rc != 0:
         raise ValueError("kor_render: bad arguments")
     return out

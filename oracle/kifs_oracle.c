@@ -64,6 +64,7 @@ typedef struct {
     float power;
     v4 c;
     int32_t sdf_iters, normal_iters, fold_iters;
+    KorExt ext; /* extension block, all zero = reference behaviour */
     /* counters (instrumented run only) */
     uint64_t n_sdf, n_inner;
 } Scene;
@@ -388,6 +389,33 @@ static v3 ray_direction(const Scene* s, int x, int y) {
     return normalize3(d);
 }
 
+/* EXTENSION (absent from the reference): soft shadow factor in [0, 1] for a hit at p with
+ * normal n.  The secondary ray starts 2*epsilon off the surface along the normal and marches
+ * towards the light direction normalize((1,1,1)) -- the direction of the reference's
+ * un-normalised light vector (entry.wgsl:17):
+ *     res = 1;  t = t0
+ *     repeat up to shadow_steps times:
+ *         h = scene_SDF(start + t * L);  if h < epsilon: return 0      (occluded)
+ *         res = min(res, (k * h) / t);   t = t + h;  if t > max_t: stop
+ *     return res
+ * Only the direct term is attenuated: diffuse = 0.1 + 0.9 * clamp(n.(1,1,1)) * res. */
+static float soft_shadow(Scene* s, v3 p, v3 n) {
+    const v3 L = normalize3((v3){1.0f, 1.0f, 1.0f});
+    const float off = 2.0f * s->epsilon;
+    const v3 start = {fma_(off, n.x, p.x), fma_(off, n.y, p.y), fma_(off, n.z, p.z)};
+    float res = 1.0f;
+    float t = s->ext.shadow_t0;
+    for (int j = 0; j < s->ext.shadow_steps; j++) {
+        v3 q = {fma_(t, L.x, start.x), fma_(t, L.y, start.y), fma_(t, L.z, start.z)};
+        float h = scene_sdf(s, q);
+        if (h < s->epsilon) return 0.0f;
+        res = min_(res, (s->ext.shadow_k * h) / t);
+        t = t + h;
+        if (t > s->ext.shadow_max_t) break;
+    }
+    return res;
+}
+
 /* Returns loop counter i; rgba = linear colour (entry.wgsl:6-29). */
 static int raymarch(Scene* s, v3 dir, float rgba[4], int* hit_out) {
     float out_r = s->background_color.x, out_g = s->background_color.y,
@@ -401,7 +429,9 @@ static int raymarch(Scene* s, v3 dir, float rgba[4], int* hit_out) {
         if (d < s->epsilon) {                                         /* :15 */
             v3 n = scene_normal(s, p);                                /* :16 */
             float ndl = (n.x + n.y) + n.z; /* dot(n, (1,1,1)), :17 */
-            float diffuse = fma_(0.9f, clamp_(ndl, 0.0f, 1.0f), 0.1f);
+            float lit = clamp_(ndl, 0.0f, 1.0f);
+            if (s->ext.soft_shadow) lit = lit * soft_shadow(s, p, n); /* extension */
+            float diffuse = fma_(0.9f, lit, 0.1f);
             out_r = diffuse * s->fractal_color.x;                     /* :19 */
             out_g = diffuse * s->fractal_color.y;
             out_b = diffuse * s->fractal_color.z;
@@ -516,6 +546,12 @@ static void* worker(void* arg) {
 int kor_render(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
                const KorIters* iters, int encode, int y0, int y1, uint8_t* out, size_t pitch,
                int nthreads) {
+    return kor_render_ext(screen, camera, options, iters, NULL, encode, y0, y1, out, pitch, nthreads);
+}
+
+int kor_render_ext(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
+                   const KorIters* iters, const KorExt* ext, int encode, int y0, int y1,
+                   uint8_t* out, size_t pitch, int nthreads) {
     if (check_args(screen, camera, options, y0, y1, out, pitch)) return -1;
     pthread_once(&g_srgb_once, srgb_init);
     if (nthreads <= 0) nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
@@ -523,6 +559,7 @@ int kor_render(const KorScreen* screen, const KorCamera* camera, const KorOption
     if (nthreads > 256) nthreads = 256;
     Job job;
     scene_init(&job.scene, screen, camera, options, iters);
+    if (ext) job.scene.ext = *ext;
     volatile int next = y0;
     job.encode = encode; job.y0 = y0; job.y1 = y1; job.w = (int)screen->width;
     job.out = out; job.pitch = pitch; job.next_row = &next;

@@ -69,6 +69,17 @@ typedef struct {
 
 enum { KOR_ENCODE_UNORM = 0, KOR_ENCODE_SRGB = 1 };
 
+/* Extension (NOT in the reference; BASELINE config 5 names it): soft shadows by a secondary
+ * march from the hit point towards the light (1,1,1).  Semantics are this project's own,
+ * stated in kifs_oracle.c:soft_shadow and mirrored by the HIP kernels. */
+typedef struct {
+    uint32_t soft_shadow; /* 0 = off (the reference's shading) */
+    int32_t shadow_steps; /* cap on secondary march steps */
+    float shadow_k;       /* penumbra sharpness: res = min(res, k * h / t) */
+    float shadow_t0;      /* first sample distance along the light ray */
+    float shadow_max_t;   /* stop once the secondary ray has travelled this far */
+} KorExt;
+
 /* Per-frame work counters (instrumented run; used for the flops/pixel figure). */
 typedef struct {
     uint64_t pixels;
@@ -86,6 +97,11 @@ typedef struct {
 int kor_render(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
                const KorIters* iters, int encode, int y0, int y1, uint8_t* out, size_t pitch,
                int nthreads);
+
+/* kor_render with the extension block (ext == NULL: identical to kor_render). */
+int kor_render_ext(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
+                   const KorIters* iters, const KorExt* ext, int encode, int y0, int y1,
+                   uint8_t* out, size_t pitch, int nthreads);
 
 /* Same, single-threaded, also filling `stats`; `steps_out` (optional, W*(y1-y0)
  * uint16) receives the loop counter `i` of every pixel (entry.wgsl:11-27). */

@@ -232,3 +232,36 @@ def test_tile_order_feedback_never_changes_pixels(gs, kifs, oracle):
     # the feedback really reordered the table (it no longer starts at the frame centre)
     first = [(int(o) & 0xffff, int(o) >> 16) for o in order[:4]]
     assert first != sorted(first, key=lambda t: (2 * t[0] + 1 - 60) ** 2 * 16 + (2 * t[1] + 1 - 135) ** 2) or True
+
+
+@pytest.mark.parametrize("scene", ["sierpinski", "torus", "julia", "bunny"])
+def test_soft_shadow_extension_matches_oracle(scene, gs, kifs, oracle):
+    """Soft shadows are an extension with no reference counterpart: the contract is the
+    oracle's soft_shadow(), and the HIP path must match it bit for bit; switched off, the
+    frame is the reference frame again."""
+    FG, PS = kifs.FractalGroup, kifs.PrimitiveShape
+    cfg = {
+        "sierpinski": (kifs.CameraData(origin_distance=3.5, phi=0.6, theta=0.5),
+                       kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, fractal_color=(250, 200, 160)), (100, 10, 10)),
+        "torus": (kifs.CameraData(origin_distance=3.5, phi=0.9, theta=-0.4),
+                  kifs.GuiData(primitive_shape=PS.Torus, fractal_color=(120, 220, 250)), (100, 10, 10)),
+        "julia": (kifs.CameraData(origin_distance=3.0, phi=0.3, theta=0.2),
+                  kifs.GuiData(fractal_group=FG.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2)), (12, 10, 10)),
+        "bunny": (kifs.CameraData(origin_distance=2.2, phi=0.6, theta=0.3),
+                  kifs.GuiData(primitive_shape=PS.Bunny, max_iterations=96), (100, 10, 10)),
+    }[scene]
+    cam, gui, iters = cfg
+    screen = kifs.ScreenData(160, 120) if scene != "bunny" else kifs.ScreenData(80, 60)
+    plain = gpu_frame(gs, screen, cam, gui, iters)
+    ext = oracle.Ext(1, 48, 8.0, 0.02, 10.0)
+    from helpers import oracle_uniforms
+    s, c, o = oracle_uniforms(oracle, kifs, (screen, cam, gui))
+    want = oracle.render(s, c, o, oracle.iters(*iters), ext=ext)
+    gs.set_extensions(soft_shadow=True, shadow_steps=48, shadow_k=8.0, shadow_t0=0.02, shadow_max_t=10.0)
+    try:
+        got = gs.render()
+    finally:
+        gs.set_extensions(soft_shadow=False)
+    assert (got == want).all(), int((got != want).any(-1).sum())
+    assert (want != plain).any(), "the shadow pass changed nothing"
+    assert (gpu_frame(gs, screen, cam, gui, iters) == plain).all()

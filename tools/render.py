@@ -27,6 +27,8 @@ if args.heatmap:
     gui = K.GuiData(**{**gui.__dict__, "is_heatmap": True, "fractal_color": (255, 255, 255)})
 with K.GraphicState(0, screen_data=screen, camera_data=w.camera, gui_data=gui) as gs:
     gs.set_iters(*w.iters)
+    if w.extensions:
+        gs.set_extensions(**w.extensions)
     if args.frames is None:
         write_png(args.out, gs.render())
         print(f"{args.out}: {screen.width}x{screen.height}, kernel {gs.last_kernel_ms():.3f} ms")
