@@ -195,6 +195,15 @@ double kifs_multi_band_ms(kifs_multi* m, int i);
  * on the launch stream), or a negative value if none completed. */
 double kifs_last_kernel_ms(kifs_ctx* ctx);
 
+/* Per-launch timing for benchmarks.  With enable != 0 every subsequent render launch is
+ * bracketed by a pair of HIP events recorded on the launch stream immediately around the
+ * render kernel (after any stream waits), kept in a ring of the latest 4096 launches;
+ * enable = n > 1 times only every n-th launch (an event pair costs a few microseconds).
+ * kifs_profile_read synchronises, reports how many launches were timed and their mean,
+ * minimum and maximum kernel duration in ms, and clears the ring. */
+int kifs_set_profiling(kifs_ctx* ctx, int enable);
+int kifs_profile_read(kifs_ctx* ctx, int* launches, double* mean_ms, double* min_ms, double* max_ms);
+
 /* Blocks until everything the context enqueued on its own stream is done. */
 int kifs_synchronize(kifs_ctx* ctx);
 

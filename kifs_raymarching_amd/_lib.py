@@ -87,6 +87,8 @@ SIGNATURES = {
     "kifs_multi_band_ms": (C.c_double, [_ctx, C.c_int]),
     "kifs_last_kernel_ms": (C.c_double, [_ctx]),
     "kifs_synchronize": (C.c_int, [_ctx]),
+    "kifs_set_profiling": (C.c_int, [_ctx, C.c_int]),
+    "kifs_profile_read": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "kifs_strerror": (C.c_char_p, [C.c_int]),
     "kifs_abi_version": (C.c_int, []),
     "kifs_eval_points": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, _f32p]),

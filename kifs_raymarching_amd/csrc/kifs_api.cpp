@@ -63,6 +63,12 @@ struct kifs_ctx {
     bool have_screen = false, have_camera = false, have_options = false;
     int sdf_iters = 100, normal_iters = 10, fold_iters = 10;  // julia.wgsl:2-3, kifs.wgsl:72
     KifsExtensions ext{};  // all zero: the reference's behaviour
+    // per-launch profiling ring (kifs_set_profiling)
+    bool profiling = false;
+    int prof_every = 1;      // time every n-th launch
+    uint64_t prof_seen = 0;  // launches seen while profiling
+    std::vector<hipEvent_t> prof_a, prof_b;
+    size_t prof_count = 0;
     double last_ms = -1.0;
     bool timing_pending = false;
     unsigned long long* d_counters = nullptr;  // diagnostics buffer, see FrameParams
@@ -365,9 +371,16 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
     if (use_feedback && k >= 2 && stream != tt->last_stream &&
         !hip_ok(hipStreamWaitEvent(stream, tt->rendered[k & 1], 0), "wait(render k-2)"))
         return KIFS_ERR_RUNTIME;  // launch k-2 wrote the same cost buffer; only matters across streams
+    const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
+    const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
+    if (timed && !hip_ok(hipEventRecord(c->prof_a[pslot], stream), "record(profile start)")) return KIFS_ERR_RUNTIME;
     hipError_t e = kifs::launch_render(P, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
     if (!hip_ok(e, "render_kernel launch")) return KIFS_ERR_RUNTIME;
+    if (timed) {
+        if (!hip_ok(hipEventRecord(c->prof_b[pslot], stream), "record(profile stop)")) return KIFS_ERR_RUNTIME;
+        ++c->prof_count;
+    }
     if (!use_feedback) {  // no bookkeeping, no events: nothing depends on this launch
         tt->launches = 0;
         tt->sort_pending = false;
@@ -453,6 +466,8 @@ void kifs_destroy(kifs_ctx* c) {
     }
     for (auto& t : c->tables)
         if (t.d_order) free_table(t);
+    for (hipEvent_t ev : c->prof_a) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->prof_b) if (ev) (void)hipEventDestroy(ev);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_srgb) (void)hipFree(c->d_srgb);
@@ -566,6 +581,46 @@ int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int enc
 
 double kifs_last_kernel_ms(kifs_ctx* c) { return c ? c->last_ms : -1.0; }
 
+int kifs_set_profiling(kifs_ctx* c, int enable) {
+    if (!c) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (enable && c->prof_a.empty()) {
+        constexpr size_t RING = 4096;
+        c->prof_a.assign(RING, nullptr);
+        c->prof_b.assign(RING, nullptr);
+        for (size_t i = 0; i < RING; ++i)
+            if (hipEventCreate(&c->prof_a[i]) != hipSuccess || hipEventCreate(&c->prof_b[i]) != hipSuccess)
+                return KIFS_ERR_RUNTIME;
+    }
+    c->profiling = enable != 0;
+    c->prof_every = enable > 1 ? enable : 1;
+    c->prof_seen = 0;
+    c->prof_count = 0;
+    return KIFS_OK;
+}
+
+int kifs_profile_read(kifs_ctx* c, int* launches, double* mean_ms, double* min_ms, double* max_ms) {
+    if (!c || !launches) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (hipDeviceSynchronize() != hipSuccess) return KIFS_ERR_RUNTIME;
+    const size_t ring = c->prof_a.size();
+    const size_t n = ring ? std::min(c->prof_count, ring) : 0;
+    double sum = 0.0, lo = 1e300, hi = 0.0;
+    size_t ok = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->prof_a[i], c->prof_b[i]) == hipSuccess) {
+            sum += ms; lo = std::min(lo, double(ms)); hi = std::max(hi, double(ms)); ++ok;
+        }
+    }
+    *launches = int(ok);
+    if (mean_ms) *mean_ms = ok ? sum / double(ok) : -1.0;
+    if (min_ms) *min_ms = ok ? lo : -1.0;
+    if (max_ms) *max_ms = ok ? hi : -1.0;
+    c->prof_count = 0;
+    return KIFS_OK;
+}
+
 int kifs_synchronize(kifs_ctx* c) {
     if (!c) return KIFS_ERR_BAD_ARG;
     DeviceGuard g(c->device);
@@ -662,9 +717,10 @@ int kifs_eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float
     if (n == 0) return KIFS_OK;
     DeviceGuard g(c->device);
     kifs::FrameParams P;
-    kifs_ctx tmp = *c;  // options-only evaluation: give fill_params a valid 1x1 screen
-    tmp.screen = {1.0f, 1.0f, 1.0f};
-    int st = fill_params(&tmp, &P);
+    const KifsScreenUniform saved_screen = c->screen;  // options-only evaluation: any valid screen does
+    c->screen = {1.0f, 1.0f, 1.0f};
+    int st = fill_params(c, &P);
+    c->screen = saved_screen;
     if (st != KIFS_OK) return st;
     float *d_pts = nullptr, *d_sdf = nullptr, *d_nrm = nullptr;
     int rc = KIFS_ERR_RUNTIME;

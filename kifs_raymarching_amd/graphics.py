@@ -286,6 +286,17 @@ class GraphicState:
         check(lib.kifs_render_async(self._ctx, stream, _device_pointer(out), pitch, y0, y1,
                                     encode), "render_async")
 
+    def set_profiling(self, every: int = 1):
+        """every = 0: off; 1: time every launch; n: every n-th launch."""
+        check(lib.kifs_set_profiling(self._ctx, int(every)), "set_profiling")
+
+    def profile_read(self):
+        """(launches, mean_ms, min_ms, max_ms) of the render kernel since the last read."""
+        n, mean, lo, hi = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        check(lib.kifs_profile_read(self._ctx, C.byref(n), C.byref(mean), C.byref(lo), C.byref(hi)),
+              "profile_read")
+        return n.value, mean.value, lo.value, hi.value
+
     def last_kernel_ms(self) -> float:
         return float(lib.kifs_last_kernel_ms(self._ctx))
 
