@@ -36,7 +36,7 @@ struct TileTable {
     uint32_t* d_order = nullptr;      // order used by the next launch
     uint32_t* d_order_alt = nullptr;  // the other half of the double buffer (the sort's target)
     uint32_t* d_cost[2] = {nullptr, nullptr};  // per-tile cost, written by launch k into [k & 1]
-    hipEvent_t rendered[2] = {nullptr, nullptr};  // recorded after launch k into [k & 1]
+    hipEvent_t rendered[2] = {nullptr, nullptr};  // [0]: after the cost-recording launch; [1]: stream changes
     hipEvent_t sorted = nullptr;      // recorded after the sort that fills d_order_alt
     uint64_t launches = 0;            // consecutive feedback launches made with this table
     hipStream_t last_stream = nullptr;  // stream of the latest of them
@@ -358,19 +358,34 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
     // small frames, where it does not pay for itself.
     const bool use_feedback = tt->feedback && tile_feedback_enabled() &&
                               c->options.fractal_group_id != uint32_t(kifs::GROUP_KIFS) && tt->count >= 2048;
-    if (use_feedback && tt->sort_pending) {  // adopt the order the side stream prepared
+    // The order is refreshed every FEEDBACK_PERIOD launches (views change slowly; the events the
+    // refresh needs cost a few microseconds each).  Within a period of launches k = 0..P-1:
+    //   k == 0: record costs, event;   k == 1: sort the costs of launch 0 on the side stream;
+    //   k == 2: adopt the new order (wait for the sort);   otherwise: a plain launch.
+    static const uint64_t FEEDBACK_PERIOD = [] {
+        const char* e = std::getenv("KIFS_FEEDBACK_PERIOD");
+        long v = e ? std::strtol(e, nullptr, 10) : 4;
+        return uint64_t(v < 3 ? 3 : v);
+    }();
+    if (use_feedback && tt->last_stream && tt->last_stream != stream) {
+        // The caller moved to another stream: order this stream after the launches of the old
+        // one, so that the buffer rotation below keeps its "nobody still reads it" guarantee.
+        if (!hip_ok(hipEventRecord(tt->rendered[1], tt->last_stream), "record(stream change)") ||
+            !hip_ok(hipStreamWaitEvent(stream, tt->rendered[1], 0), "wait(stream change)"))
+            return KIFS_ERR_RUNTIME;
+    }
+    if (use_feedback) tt->last_stream = stream;
+    const uint64_t k = use_feedback ? tt->launches % FEEDBACK_PERIOD : 0;
+    if (use_feedback && k == 2 && tt->sort_pending) {  // adopt the order the side stream prepared
         if (!hip_ok(hipStreamWaitEvent(stream, tt->sorted, 0), "wait(sorted)")) return KIFS_ERR_RUNTIME;
         std::swap(tt->d_order, tt->d_order_alt);
         tt->sort_pending = false;
     }
-    const uint64_t k = tt->launches;
+    const bool record_costs = use_feedback && k == 0;
     P.tile_order = tt->d_order;
     P.tile_count = tt->count;
-    P.tile_cost = use_feedback ? tt->d_cost[k & 1] : nullptr;
+    P.tile_cost = record_costs ? tt->d_cost[0] : nullptr;
     P.workgroups_per_cu = residency_for(P, c->options.fractal_group_id, h, tt->count);
-    if (use_feedback && k >= 2 && stream != tt->last_stream &&
-        !hip_ok(hipStreamWaitEvent(stream, tt->rendered[k & 1], 0), "wait(render k-2)"))
-        return KIFS_ERR_RUNTIME;  // launch k-2 wrote the same cost buffer; only matters across streams
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
     const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
     if (timed && !hip_ok(hipEventRecord(c->prof_a[pslot], stream), "record(profile start)")) return KIFS_ERR_RUNTIME;
@@ -386,17 +401,20 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
         tt->sort_pending = false;
         return KIFS_OK;
     }
-    if (!hip_ok(hipEventRecord(tt->rendered[k & 1], stream), "record(render)")) return KIFS_ERR_RUNTIME;
-    tt->launches = k + 1;
-    tt->last_stream = stream;
-    if (k >= 1) {
-        // sort the costs of launch k-1 into d_order_alt (the order launch k-1 used, now idle)
+    tt->launches += 1;
+    if (record_costs) {
+        // Launch k = 0 of the period wrote d_cost[0].  The previous sort (period before) read it
+        // and finished before that period's launch 2 started, i.e. long ago on this timeline.
+        if (!hip_ok(hipEventRecord(tt->rendered[0], stream), "record(render)")) return KIFS_ERR_RUNTIME;
+    } else if (k == 1) {
+        // sort those costs into d_order_alt: the buffer last read by launches of the period
+        // before the previous adoption, all of which precede launch 0 of this period
         if (!c->side_stream &&
             !hip_ok(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "side stream"))
             return KIFS_ERR_RUNTIME;
         const uint32_t tiles_x = uint32_t((P.width + kifs::TILE_W - 1) / kifs::TILE_W);
-        if (!hip_ok(hipStreamWaitEvent(c->side_stream, tt->rendered[(k - 1) & 1], 0), "wait(render k-1)") ||
-            !hip_ok(kifs::launch_tile_order(tt->d_cost[(k - 1) & 1], tt->d_order_alt, tt->count, tiles_x,
+        if (!hip_ok(hipStreamWaitEvent(c->side_stream, tt->rendered[0], 0), "wait(render 0)") ||
+            !hip_ok(kifs::launch_tile_order(tt->d_cost[0], tt->d_order_alt, tt->count, tiles_x,
                                             c->side_stream), "tile_order_kernel launch") ||
             !hip_ok(hipEventRecord(tt->sorted, c->side_stream), "record(sorted)"))
             return KIFS_ERR_RUNTIME;
