@@ -96,6 +96,49 @@ def cpu_baseline(w, seconds):
             "sample": sample + f", C oracle ({O.lib()._variant}), {cores} threads"}
 
 
+VALU_F32_PEAK_TFLOPS = 157.3  # MI355X vector f32 (MI355X_MICROARCH.md); the path has no MFMA work
+
+
+def work_count(w, kernel_s):
+    """Secondary figure of SURVEY 8(d): algorithmic flops of one frame, counted by the
+    instrumented CPU oracle (march steps, Julia iterations / Sierpinski folds, hits), against
+    the f32 vector peak.  Flop model: 15 per march step, 24 per Julia
+    iteration or 40 per fold, 4 for the log/sqrt/divide tail of a Julia step, and per hit
+    40 * normal_iters (Julia Jacobian) -- the six extra SDF calls of a KIFS normal are already
+    in the step and fold counts."""
+    import oracle as O
+    import kifs_raymarching_amd as K
+
+    ub = K.uniform_bytes
+    s = O.from_bytes(O.Screen, ub(w.screen.into_buffer_data()))
+    c = O.from_bytes(O.Camera, ub(w.camera.into_buffer_data()))
+    o = O.from_bytes(O.Options, ub(w.gui.into_buffer_data()))
+    it = O.iters(*w.iters)
+    W, H = w.screen.width, w.screen.height
+    stride = max(1, (W * H + (1 << 22) - 1) >> 22)  # count every stride-th row of big frames
+    steps = inner = hits = calls = rows = 0
+    bands = [(0, H)] if stride == 1 else [(y, y + 1) for y in range(stride // 2, H, stride)]
+    for y0, y1 in bands:
+        _, _, st = O.render_stats(s, c, o, it, y0=y0, y1=y1)
+        steps += st.march_steps
+        inner += st.inner_iters
+        hits += st.hits
+        calls += st.sdf_calls
+        rows += y1 - y0
+    scale = H / rows
+    julia = int(w.gui.fractal_group) != 0
+    flops = (15.0 * calls + (24.0 if julia else 40.0) * inner + (4.0 * steps if julia else 0.0)
+             + (40.0 * w.iters[1] * hits if julia else 0.0)) * scale
+    tflops = flops / kernel_s / 1e12
+    return {"bound": "valu-f32", "achieved": round(tflops, 3), "peak": VALU_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tflops / VALU_F32_PEAK_TFLOPS, 5),
+            "flops_per_pixel": round(flops / (W * H), 1),
+            "march_steps_per_pixel": round(steps * scale / (W * H), 2),
+            "inner_iterations_per_step": round(inner / max(calls, 1), 3),
+            "hit_fraction": round(hits * scale / (W * H), 5),
+            "sample": "whole frame" if stride == 1 else f"every {stride}th row, scaled"}
+
+
 def pmc_traffic(workload_key):
     """HBM bytes per launch from the committed rocprofv3 PMC pass, if one exists."""
     p = ROOT / "profiles" / "pmc_traffic.json"
@@ -265,6 +308,7 @@ def main():
             out["gathered_frame_equals_single_gpu_frame"] = check
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+            out["roofline"]["secondary"] = work_count(w, launch_s)
         print(json.dumps(out), flush=True)
 
     gs.close()

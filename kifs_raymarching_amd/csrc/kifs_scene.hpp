@@ -242,7 +242,8 @@ KIFS_DEV V3 tetrahedral_fold(V3 p) {  // kifs.wgsl:56-66
 // x / sqrt(2) with the reciprocal folded into constants: two residual corrections around
 // x * (1/c).  tools/verify/div_const2.c checks all 2^32 inputs: bit-identical to the correctly
 // rounded quotient for every 2^-102 <= |x| < 2^127 (and for NaN); it is NOT exact for tinier
-// values, zeros and infinities, which is what fold_fast_ok() screens for.
+// values, zeros and infinities (sierpinski_folds screens for those).  This function is the readable
+// statement of the sequence KIFS_MIRROR_SD spells out in assembly.
 KIFS_DEV float div_sqrt2_ranged(float x) {
     const float c = sqrt_(2.0f);
     const float inv = 1.0f / c;
@@ -256,33 +257,116 @@ KIFS_DEV float div_sqrt2_ranged(float x) {
 // The fold with the ranged division; `lo`/`hi` receive min/max |x| over the three quotients'
 // numerators so that the caller can validate the whole fold with two compares.  (min3/max3
 // skip NaN operands, which is fine: a NaN coordinate gives a NaN estimate on either path.)
-KIFS_DEV V3 tetrahedral_fold_ranged(V3 p, float& lo, float& hi) {
-    float x1 = p.x + p.y;
-    mirror_apply(div_sqrt2_ranged(x1), p.x, p.y);
-    float x2 = p.y + p.z;
-    mirror_apply(div_sqrt2_ranged(x2), p.y, p.z);
-    float x3 = p.x + p.z;
-    mirror_apply(div_sqrt2_ranged(x3), p.x, p.z);
-    lo = __builtin_fminf(__builtin_fminf(abs_(x1), abs_(x2)), abs_(x3));
-    hi = __builtin_fmaxf(__builtin_fmaxf(abs_(x1), abs_(x2)), abs_(x3));
-    return p;
+// One mirror of the fold in the long-ray loop below: x = a + b; sd = x / sqrt(2) by the ranged
+// division (q in v46, residuals in v47); m = min(sd, 0) -- the hardware minimum, see below --
+// left in v46 for the caller's two updates  p -= m * (2/sqrt(2)).
+#define KIFS_MIRROR_SD(x, a, b)                                                            \
+    "v_add_f32_e32 " x ", " a ", " b "\n"                                                  \
+    "v_mul_f32_e32 v46, 0x3f3504f3, " x "\n"         /* q0 = x * I */                      \
+    "v_fmamk_f32 v47, v46, 0xbfb504f3, " x "\n"      /* e1 = fma(-c, q0, x) */             \
+    "v_fmac_f32_e32 v46, 0x3f3504f3, v47\n"          /* q1 = fma(e1, I, q0) */             \
+    "v_fmamk_f32 v47, v46, 0xbfb504f3, " x "\n"      /* e2 = fma(-c, q1, x) */             \
+    "v_fmac_f32_e32 v46, 0x3f3504f3, v47\n"          /* q2 = fma(e2, I, q1) */             \
+    "v_min_f32_e32 v46, 0, v46\n"
+
+// One fold + scale step of kifs.wgsl:72-78 for the lanes in EXEC, then EXEC &= n2 < stop.
+//   v[40:41] = [x, y]   v42 = z   v43 = n2   v44 = scale   v45 = smallest numerator key so far
+//   v[46:47] division scratch   v48-v50 numerators   s[76:77] = [-2/sqrt(2), -]
+#define KIFS_FOLD_STEP                                                                     \
+    KIFS_MIRROR_SD("v48", "v40", "v41")                                                    \
+    "v_pk_fma_f32 v[40:41], v[46:47], s[76:77], v[40:41] op_sel_hi:[0,0,1]\n"              \
+    KIFS_MIRROR_SD("v49", "v41", "v42")                                                    \
+    "v_fmac_f32_e32 v41, 0xbfb504f3, v46\n"                                                \
+    "v_fmac_f32_e32 v42, 0xbfb504f3, v46\n"                                                \
+    KIFS_MIRROR_SD("v50", "v40", "v42")                                                    \
+    "v_fmac_f32_e32 v40, 0xbfb504f3, v46\n"                                                \
+    "v_fmac_f32_e32 v42, 0xbfb504f3, v46\n"                                                \
+    "v_lshl_add_u32 v48, v48, 1, -1\n"      /* numerator bits without sign, zero -> 2^32-1 */ \
+    "v_lshl_add_u32 v49, v49, 1, -1\n"                                                     \
+    "v_lshl_add_u32 v50, v50, 1, -1\n"                                                     \
+    "v_min3_u32 v45, v48, v49, v45\n"                                                      \
+    "v_pk_fma_f32 v[40:41], v[40:41], 2.0, -1.0 op_sel_hi:[1,0,0]\n"   /* p = 2 p - 1 */    \
+    "v_fma_f32 v42, v42, 2.0, -1.0\n"                                                      \
+    "v_min_u32_e32 v45, v50, v45\n"                                                        \
+    "v_add_f32_e32 v44, v44, v44\n"                                    /* scale *= 2 */     \
+    "v_mul_f32_e32 v43, v40, v40\n"                                    /* n2 = dot(p, p) */ \
+    "v_fmac_f32_e32 v43, v41, v41\n"                                                       \
+    "v_fmac_f32_e32 v43, v42, v42\n"                                                       \
+    "v_cmpx_gt_f32_e32 vcc, %[stop], v43\n"
+
+// The fold loop of the Sierpinski estimate, hand-scheduled: 41 instructions per fold where the
+// compiler's version of the same arithmetic has 52 (and a taken branch every fold; here every
+// second).  Exact rewrites make the difference:
+//  * the division by sqrt(2) is div_sqrt2_ranged (above), valid for 2^-102 <= |x| < 2^127.  The
+//    upper bound always holds: a lane folds only while n2 < stop, so n2 is finite, every
+//    coordinate is below 2^64.1 and no numerator can reach 2^67.
+//  * x = +-0 (every pixel on the image diagonal of an axis-aligned view starts with y + z = 0)
+//    is fine too: the sequence returns a zero, possibly of the other sign, the mirror then adds
+//    a signed zero to both coordinates, and p = 2 p - 1 (fma(2, +-0, -1) = -1) forgets the sign
+//    of a zero coordinate before anything but another signed-zero sum can see it.
+//  * what is NOT covered is 0 < |x| < 2^-102.  Each numerator contributes the key
+//    (bits << 1) - 1 (sign dropped; zero wraps to 2^32 - 1) to a running unsigned minimum,
+//    checked once after the loop: a wave with a key below that of 2^-102 (practically never) is
+//    re-evaluated by the caller with true divisions.
+//  * min_(sd, 0) is the hardware minimum: they differ only for sd = -0 (sign of a zero again)
+//    and for NaN, and a NaN numerator means a coordinate is NaN already and stays NaN on both
+//    paths (the estimate is NaN either way);
+//  * 2 * m is exact, so fma(-(2 m), 1/sqrt(2), p) = fma(m, -(2/sqrt(2)), p) bit for bit.
+// `lanes`: lanes that take part.  Returns false when the result must be recomputed exactly.
+KIFS_DEV bool sierpinski_folds(const FrameParams& P, V3& p, float& n2, float& scale,
+                                unsigned long long lanes) {
+    F2 xy{p.x, p.y}, q;
+    float z = p.z, x1, x2, x3;
+    unsigned lo = 0xffffffffu;
+    const F2 knn{-2.0f * (1.0f / sqrt_(2.0f)), 0.0f};
+    int n = P.fold_iters;
+    unsigned long long saved_exec;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n"
+        "s_cmp_lt_i32 %[n], 1\n"
+        "s_cbranch_scc1 1f\n"
+        "s_and_b64 exec, exec, %[lanes]\n"   // lanes whose result nobody reads do not fold
+        "v_cmpx_gt_f32_e32 vcc, %[stop], v43\n"
+        "s_cbranch_execz 1f\n"
+        "0:\n"
+        KIFS_FOLD_STEP
+        "s_sub_u32 %[n], %[n], 1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 1f\n"
+        "s_cbranch_execz 1f\n"
+        KIFS_FOLD_STEP
+        "s_sub_u32 %[n], %[n], 1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 1f\n"
+        "s_cbranch_execnz 0b\n"
+        "1:\n"
+        "s_mov_b64 exec, %[save]\n"
+        : "+{v[40:41]}"(xy), "+{v42}"(z), "+{v43}"(n2), "+{v44}"(scale), "+{v45}"(lo),
+          "=&{v[46:47]}"(q), "=&{v48}"(x1), "=&{v49}"(x2), "=&{v50}"(x3), [save] "=&s"(saved_exec),
+          [n] "+s"(n)
+        : [stop] "s"(P.fold_n2_stop), "{s[76:77]}"(knn), [lanes] "s"(lanes)
+        : "vcc", "scc");
+    p = V3{xy.x, xy.y, z};
+    return __builtin_amdgcn_ballot_w64(lo < ((25u << 24) - 1u)) == 0ull;  // biased exponent of 2^-102 is 25
 }
 
-KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p) {  // kifs.wgsl:68-81
+// `lanes`: the lanes whose estimate the caller will use (the others get an unspecified value).
+KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p, unsigned long long lanes) {  // kifs.wgsl:68-81
     // The loop condition `r < max_distance` is evaluated on the squared norm (exact: see
     // FrameParams::fold_n2_stop), so the square root is taken once, after the loop.
+    const V3 p0 = p;
     float scale = 1.0f;
     float n2 = dot(p, p);
-    for (int i = 0; i < P.fold_iters && n2 < P.fold_n2_stop; ++i) {
-        float lo, hi;
-        V3 f = tetrahedral_fold_ranged(p, lo, hi);
-        const bool in_range = (lo >= 0x1p-102f) && (hi < 0x1p127f);
-        // a lane outside the verified range (practically never) sends the wave through the
-        // fold with true divisions; for every in-range lane the two folds agree bit for bit
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!in_range) != 0ull, 0)) f = tetrahedral_fold(p);
-        p = V3{fmaf_(2.0f, f.x, -1.0f), fmaf_(2.0f, f.y, -1.0f), fmaf_(2.0f, f.z, -1.0f)};
-        scale = scale * 2.0f;
+    if (__builtin_expect(!sierpinski_folds(P, p, n2, scale, lanes), 0)) {
+        p = p0;
+        scale = 1.0f;
         n2 = dot(p, p);
+        for (int i = 0; i < P.fold_iters && n2 < P.fold_n2_stop; ++i) {
+            V3 f = tetrahedral_fold(p);
+            p = V3{fmaf_(2.0f, f.x, -1.0f), fmaf_(2.0f, f.y, -1.0f), fmaf_(2.0f, f.z, -1.0f)};
+            scale = scale * 2.0f;
+            n2 = dot(p, p);
+        }
     }
     return (sqrt_(n2) - 2.0f) / scale;
 }
@@ -332,7 +416,7 @@ KIFS_DEV float bunny_sdf(V3 p) {  // kifs.wgsl:84-137; weights in constant memor
 }
 
 template <int PRIM>
-KIFS_DEV float kifs_sdf(const FrameParams& P, V3 p) {  // kifs.wgsl:139-155
+KIFS_DEV float kifs_sdf(const FrameParams& P, V3 p, unsigned long long lanes = ~0ull) {  // kifs.wgsl:139-155
     if constexpr (PRIM == PRIM_SPHERE) {
         return length(p) - 1.0f;
     } else if constexpr (PRIM == PRIM_CYLINDER) {
@@ -347,7 +431,7 @@ KIFS_DEV float kifs_sdf(const FrameParams& P, V3 p) {  // kifs.wgsl:139-155
         V2 q{length(V2{p.x, p.y}) - 1.0f, p.z};
         return length(q) - 0.3f;
     } else if constexpr (PRIM == PRIM_SIERPINSKI) {
-        return sierpinski_sdf(P, p);
+        return sierpinski_sdf(P, p, lanes);
     } else if constexpr (PRIM == PRIM_BUNNY) {
         return bunny_sdf(p);
     } else {
@@ -367,11 +451,12 @@ KIFS_DEV V3 kifs_normal(const FrameParams& P, V3 p) {  // kifs.wgsl:157-167
     return normalize(V3{dx, dy, dz});
 }
 
+// `lanes`: mask of the lanes whose estimate is used; a scene may skip the others' work.
 template <int GROUP, int PRIM>
-KIFS_DEV float scene_sdf(const FrameParams& P, V3 p) {
+KIFS_DEV float scene_sdf(const FrameParams& P, V3 p, unsigned long long lanes = ~0ull) {
     if constexpr (GROUP == GROUP_JULIA) return julia_sdf(P, p);
     else if constexpr (GROUP == GROUP_GENJULIA) return genjulia_sdf(P, p);
-    else return kifs_sdf<PRIM>(P, p);
+    else return kifs_sdf<PRIM>(P, p, lanes);
 }
 
 template <int GROUP, int PRIM>
@@ -395,9 +480,6 @@ KIFS_DEV V3 ray_direction(const FrameParams& P, int x, int y) {
 // Secondary march from the hit point towards the light, operation for operation as
 // specified in include/kifs_hip.h (KifsExtensions).  `lanes_hit` selects the lanes that take part; the loop leaves
 // when none of them is still marching.
-template <int GROUP, int PRIM>
-KIFS_DEV float scene_sdf(const FrameParams& P, V3 p);
-
 template <int GROUP, int PRIM>
 KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit) {
     const V3 L = normalize(V3{1.0f, 1.0f, 1.0f});
@@ -800,7 +882,7 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
         // The SDF is evaluated for every lane (stopped lanes hold a valid old position, their
         // result is discarded): no divergent region around the expensive part, the state update
         // is a handful of selects.
-        const float d = scene_sdf<GROUP, PRIM>(P, p);
+        const float d = scene_sdf<GROUP, PRIM>(P, p, __builtin_amdgcn_ballot_w64(marching));
         const bool h = marching && (d < P.epsilon);
         const bool go = marching && !h;
         hit = hit || h;  // break leaves i un-incremented (:20)
