@@ -64,6 +64,15 @@ WORKLOADS = {
     "ref_julia_1080p": Workload("1920x1080 Julia, reference constants (100/10), GUI default c",
                                 ScreenData(1920, 1080),
                                 _julia(256, c=(-0.1, 0.6, 0.9, -0.3)), (100, 10, 10)),
+    # the reference's third pipeline and its last primitive
+    "n1_genjulia_1080p": Workload("1920x1080 generalised Julia, power 8, reference constants (100/10)",
+                                  ScreenData(1920, 1080),
+                                  GuiData(max_iterations=256, fractal_group=FractalGroup.GeneralizedJuliaSet,
+                                          power=8.0, constant=(-0.1, 0.6, 0.9, -0.3)), (100, 10, 10)),
+    "n2_bunny_1080p": Workload("1920x1080 KIFS bunny (neural SDF), 256 steps",
+                               ScreenData(1920, 1080),
+                               GuiData(max_iterations=256, fractal_group=FractalGroup.KaleidoscopicIFS,
+                                       primitive_shape=PrimitiveShape.Bunny), (100, 10, 10)),
 }
 
 HEADLINE = "cfg2_julia_1080p"

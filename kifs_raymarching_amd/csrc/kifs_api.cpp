@@ -359,7 +359,9 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
     // does not pay for itself.
     // KIFS frames gain from it only when they are large (8K: 2.58 -> 2.23 ms; 1080p: nothing).
     const bool is_kifs = c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS);
-    const bool use_feedback = tt->feedback && tile_feedback_mode() != 0 &&
+    // (the bunny's quad kernel records no costs)
+    const bool records_costs = !(is_kifs && c->options.primitive_id == uint32_t(kifs::PRIM_BUNNY));
+    const bool use_feedback = tt->feedback && tile_feedback_mode() != 0 && records_costs &&
                               tt->count >= ((is_kifs && tile_feedback_mode() < 2) ? 16384u : 2048u);
     // The order is refreshed every FEEDBACK_PERIOD launches (views change slowly; the events the
     // refresh needs cost a few microseconds each).  Within a period of launches k = 0..P-1:

@@ -96,6 +96,58 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
         P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
 }
 
+// The bunny primitive with four lanes per pixel (see bunny_sdf_quad in kifs_scene.hpp): a
+// workgroup renders a quarter of a 32 x 8 tile, rows [2 sub, 2 sub + 2); wave w owns the 8 x 2
+// pixels at columns [8w, 8w + 8), lane -> pixel lane >> 2, column group lane & 3.  Same tile
+// order table, same LDS-staged store (two full 128-byte rows per workgroup).
+__global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const FrameParams P) {
+    __shared__ float s_srgb[256];
+    __shared__ uint32_t s_tile[2][TILE_W];
+
+    const int tid = threadIdx.x;
+    const bool srgb = (P.encode == 1);
+    if (srgb) s_srgb[tid] = P.srgb_table[tid];
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int pixel = lane >> 2, group = lane & 3;
+    const int lx = (wave << 3) | (pixel & 7);
+    const int ly = pixel >> 3;
+    const uint32_t tile = P.tile_order[blockIdx.x >> 2];
+    const int sub = int(blockIdx.x & 3u);
+    const int tile_x = int(tile & 0xffffu) * TILE_W;
+    const int tile_y = int(tile >> 16) * TILE_H + 2 * sub;  // row offset within the band
+    const int x = tile_x + lx;
+    const int y = P.y0 + tile_y + ly;
+    const bool valid = (x < P.width) && (y < P.y1);
+
+    V3 colour{0.0f, 0.0f, 0.0f};
+    int steps = 0;
+    if (__ballot(valid) != 0ull) {
+        V3 dir = ray_direction(P, x, y);
+        colour = raymarch_bunny_quad(P, dir, valid, group, steps);
+    }
+    (void)steps;
+    __syncthreads();  // s_srgb visible
+    uint32_t r, g, b;
+    if (srgb) {
+        r = srgb8(colour.x, s_srgb);
+        g = srgb8(colour.y, s_srgb);
+        b = srgb8(colour.z, s_srgb);
+    } else {
+        r = unorm8(colour.x);
+        g = unorm8(colour.y);
+        b = unorm8(colour.z);
+    }
+    if (group == 0) s_tile[ly][lx] = r | (g << 8) | (b << 16) | 0xff000000u;
+    __syncthreads();
+    if (tid < 2 * TILE_W) {
+        const int sx = tid & (TILE_W - 1), sy = tid >> 5;
+        const int ox = tile_x + sx;
+        const int oy = tile_y + sy;
+        if (ox < P.width && (P.y0 + oy) < P.y1) P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
+    }
+}
+
 // Dynamic LDS requested only to cap how many workgroups share a CU (the kernel never touches
 // it); the cap itself is decided on the host (residency_for() in kifs_api.cpp).
 // KIFS_LDS_PAD=<bytes> overrides it (tuning).
@@ -136,6 +188,11 @@ static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
     return hipGetLastError();
 }
 
+static hipError_t launch_bunny_quad(const FrameParams& P, hipStream_t stream) {
+    hipLaunchKernelGGL(render_bunny_quad_kernel, dim3(P.tile_count * 4u), dim3(BLOCK), 0, stream, P);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitive,
                          hipStream_t stream) {
     if (P.y1 <= P.y0 || P.width <= 0 || P.tile_count == 0) return hipSuccess;
@@ -149,7 +206,7 @@ hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitiv
         case PRIM_BOX: return launch_variant<GROUP_KIFS, PRIM_BOX>(P, stream);
         case PRIM_TORUS: return launch_variant<GROUP_KIFS, PRIM_TORUS>(P, stream);
         case PRIM_SIERPINSKI: return launch_variant<GROUP_KIFS, PRIM_SIERPINSKI>(P, stream);
-        case PRIM_BUNNY: return launch_variant<GROUP_KIFS, PRIM_BUNNY>(P, stream);
+        case PRIM_BUNNY: return launch_bunny_quad(P, stream);
         default: return launch_variant<GROUP_KIFS, PRIM_OTHER>(P, stream);  // kifs.wgsl:154
         }
     default: return hipErrorInvalidValue;

@@ -439,16 +439,18 @@ KIFS_DEV float kifs_sdf(const FrameParams& P, V3 p, unsigned long long lanes = ~
     }
 }
 
-template <int PRIM>
-KIFS_DEV V3 kifs_normal(const FrameParams& P, V3 p) {  // kifs.wgsl:157-167
-    const float h = P.epsilon;
-    float dx = kifs_sdf<PRIM>(P, V3{p.x + h, p.y + 0.0f, p.z + 0.0f}) -
-               kifs_sdf<PRIM>(P, V3{p.x - h, p.y - 0.0f, p.z - 0.0f});
-    float dy = kifs_sdf<PRIM>(P, V3{p.x + 0.0f, p.y + h, p.z + 0.0f}) -
-               kifs_sdf<PRIM>(P, V3{p.x - 0.0f, p.y - h, p.z - 0.0f});
-    float dz = kifs_sdf<PRIM>(P, V3{p.x + 0.0f, p.y + 0.0f, p.z + h}) -
-               kifs_sdf<PRIM>(P, V3{p.x - 0.0f, p.y - 0.0f, p.z - h});
+// Central differences with h = epsilon, no division by 2h (kifs.wgsl:157-167), for any estimate.
+template <class Sdf>
+KIFS_DEV V3 normal_fd(float h, V3 p, Sdf sdf) {
+    float dx = sdf(V3{p.x + h, p.y + 0.0f, p.z + 0.0f}) - sdf(V3{p.x - h, p.y - 0.0f, p.z - 0.0f});
+    float dy = sdf(V3{p.x + 0.0f, p.y + h, p.z + 0.0f}) - sdf(V3{p.x - 0.0f, p.y - h, p.z - 0.0f});
+    float dz = sdf(V3{p.x + 0.0f, p.y + 0.0f, p.z + h}) - sdf(V3{p.x - 0.0f, p.y - 0.0f, p.z - h});
     return normalize(V3{dx, dy, dz});
+}
+
+template <int PRIM>
+KIFS_DEV V3 kifs_normal(const FrameParams& P, V3 p) {
+    return normal_fd(P.epsilon, p, [&](V3 q) { return kifs_sdf<PRIM>(P, q); });
 }
 
 // `lanes`: mask of the lanes whose estimate is used; a scene may skip the others' work.
@@ -480,8 +482,8 @@ KIFS_DEV V3 ray_direction(const FrameParams& P, int x, int y) {
 // Secondary march from the hit point towards the light, operation for operation as
 // specified in include/kifs_hip.h (KifsExtensions).  `lanes_hit` selects the lanes that take part; the loop leaves
 // when none of them is still marching.
-template <int GROUP, int PRIM>
-KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit) {
+template <class Sdf>
+KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit, Sdf sdf) {
     const V3 L = normalize(V3{1.0f, 1.0f, 1.0f});
     const float off = 2.0f * P.epsilon;
     const V3 start{fmaf_(off, n.x, p.x), fmaf_(off, n.y, p.y), fmaf_(off, n.z, p.z)};
@@ -491,7 +493,7 @@ KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit) {
     for (int j = 0; __builtin_amdgcn_ballot_w64(marching) != 0ull; ++j) {
         if (marching) {
             const V3 q{fmaf_(t, L.x, start.x), fmaf_(t, L.y, start.y), fmaf_(t, L.z, start.z)};
-            const float h = scene_sdf<GROUP, PRIM>(P, q);
+            const float h = sdf(q, ~0ull);
             if (h < P.epsilon) {
                 res = 0.0f;
                 marching = false;
@@ -831,7 +833,7 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
         V3 n = julia_normal(P, p);
         float ndl = (n.x + n.y) + n.z;
         float lit = clamp_(ndl, 0.0f, 1.0f);
-        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow<GROUP_JULIA, 0>(P, p, n, true);
+        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow(P, p, n, true, [&](V3 q, unsigned long long) { return julia_sdf(P, q); });
         float diffuse = fmaf_(0.9f, lit, 0.1f);
         colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
                     diffuse * P.fractal_color.z};
@@ -848,9 +850,18 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
 // t >= max_distance.  The loop leaves as soon as __ballot says no lane is still
 // marching (wave-level early ray termination); normals are evaluated once, after
 // the loop, for the lanes that hit, so that divergent work is bunched together.
-template <int GROUP, int PRIM>
-KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
-    if constexpr (GROUP == GROUP_JULIA) return raymarch_julia(P, dir, valid, steps);
+// A ray that can never come within the cull radius of the origin (see fill_params): decided at
+// ray set-up from the closest approach of the ray's line.
+KIFS_DEV bool ray_never_inside(const FrameParams& P, V3 dir) {
+    const float oo = dot(P.origin, P.origin);
+    const float b = -dot(P.origin, dir);
+    const float c2 = fmaf_(-b, b, oo);
+    return (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
+}
+
+// `sdf(p, lanes)`: the scene's estimate (lanes = whose value is used); `normal(p)`: its normal.
+template <class Sdf, class Normal>
+KIFS_DEV V3 raymarch_with(const FrameParams& P, V3 dir, bool valid, int& steps, Sdf sdf, Normal normal) {
     float t = 0.0f;
     V3 p = P.origin;
     bool hit = false;
@@ -863,13 +874,7 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
     // d(p) >= |p| - B, so a ray that never comes within R = B + epsilon of the origin, or a lane
     // outside R and moving away, can never satisfy `d < epsilon`.  Not in heatmap mode.
     const bool cull = (P.is_heatmap == 0u) && (P.cull_n2 > 0.0f);  // wave-uniform
-    if (cull) {
-        const float oo = dot(P.origin, P.origin);
-        const float b = -dot(P.origin, dir);
-        const float c2 = fmaf_(-b, b, oo);
-        const bool never_inside = (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
-        marching = marching && !never_inside;
-    }
+    if (cull) marching = marching && !ray_never_inside(P, dir);
     while (__builtin_amdgcn_ballot_w64(marching) != 0ull) {
         // a ray still marching after 32 steps is on the frame's critical path: issue it first
         if (trips == 32) __builtin_amdgcn_s_setprio(3);
@@ -882,7 +887,7 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
         // The SDF is evaluated for every lane (stopped lanes hold a valid old position, their
         // result is discarded): no divergent region around the expensive part, the state update
         // is a handful of selects.
-        const float d = scene_sdf<GROUP, PRIM>(P, p, __builtin_amdgcn_ballot_w64(marching));
+        const float d = sdf(p, __builtin_amdgcn_ballot_w64(marching));
         const bool h = marching && (d < P.epsilon);
         const bool go = marching && !h;
         hit = hit || h;  // break leaves i un-incremented (:20)
@@ -899,10 +904,10 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
     steps = trips;
     V3 colour = P.background_color;
     if (hit) {
-        V3 n = scene_normal<GROUP, PRIM>(P, p);
+        V3 n = normal(p);
         float ndl = (n.x + n.y) + n.z;  // dot(n, (1,1,1)): the light is not normalised (:17)
         float lit = clamp_(ndl, 0.0f, 1.0f);
-        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow<GROUP, PRIM>(P, p, n, true);
+        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow(P, p, n, true, sdf);
         float diffuse = fmaf_(0.9f, lit, 0.1f);
         colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
                     diffuse * P.fractal_color.z};
@@ -912,6 +917,98 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
         colour = V3{f * P.fractal_color.x, f * P.fractal_color.y, f * P.fractal_color.z};
     }
     return colour;
+}
+
+template <int GROUP, int PRIM>
+KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
+    if constexpr (GROUP == GROUP_JULIA) return raymarch_julia(P, dir, valid, steps);
+    return raymarch_with(
+        P, dir, valid, steps,
+        [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); },
+        [&](V3 q) { return scene_normal<GROUP, PRIM>(P, q); });
+}
+
+// ---- the bunny, four lanes per pixel -------------------------------------------------------
+// The bunny network (kifs.wgsl:84-137) is 3000 instructions per estimate when one lane does it
+// all, and a frame's run time is the longest ray's estimates back to back (a lone wave issues
+// one instruction per ~5 cycles whatever it is).  But the network is four independent column
+// groups per layer: lane j of a quad computes group j of its pixel -- f0[j], f1[j], f2[j] and
+// the j-th partial dot product -- reading the other groups' activations through DPP quad_perm
+// operands (no extra instructions, no LDS).  A wave then holds 16 pixels and an estimate is
+// ~700 instructions per lane; every value is produced by the same operation sequence as in
+// bunny_sdf, so the result is bit-identical.  The four lanes of a quad carry identical ray
+// state, which keeps all control flow quad-uniform (DPP never reads an inactive lane).
+struct BunnyQuad {  // the weights of column group j, resident in VGPRs
+    float w0[16], w1[4][16], b1[4], w2[4][16], b2[4], wo[4];
+};
+
+KIFS_DEV void bunny_quad_load(BunnyQuad& W, int j) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) W.w0[e] = KIFS_BUNNY_L0[j][e];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            W.w1[m][e] = KIFS_BUNNY_L1[j][m][e];
+            W.w2[m][e] = KIFS_BUNNY_L2[j][m][e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        W.b1[e] = KIFS_BUNNY_B1[j][e];
+        W.b2[e] = KIFS_BUNNY_B2[j][e];
+        W.wo[e] = KIFS_BUNNY_OUT[j][e];
+    }
+}
+
+template <int M>
+KIFS_DEV float quad_lane(float v) {  // v of lane M of the caller's quad
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), M * 0x55, 0xf, 0xf, true));
+}
+template <int M>
+KIFS_DEV V4 quad_lane4(V4 v) {
+    return V4{quad_lane<M>(v.x), quad_lane<M>(v.y), quad_lane<M>(v.z), quad_lane<M>(v.w)};
+}
+
+KIFS_DEV float bunny_sdf_quad(const BunnyQuad& W, V3 p) {
+    if (dot(p, p) > 1.0f) return length(p) - 0.8f;
+    V4 q{p.x * -1.0f, p.z * 1.0f, p.y * -1.0f, 1.0f};
+    const V4 f0 = sin4(mat4_vec(W.w0, q));
+    V4 a = mat4_vec(W.w1[0], quad_lane4<0>(f0));
+    a = add4(a, mat4_vec(W.w1[1], quad_lane4<1>(f0)));
+    a = add4(a, mat4_vec(W.w1[2], quad_lane4<2>(f0)));
+    a = add4(a, mat4_vec(W.w1[3], quad_lane4<3>(f0)));
+    a = add4(a, ld4(W.b1));
+    const V4 f1 = add4(sin4(a), f0);
+    a = mat4_vec(W.w2[0], quad_lane4<0>(f1));
+    a = add4(a, mat4_vec(W.w2[1], quad_lane4<1>(f1)));
+    a = add4(a, mat4_vec(W.w2[2], quad_lane4<2>(f1)));
+    a = add4(a, mat4_vec(W.w2[3], quad_lane4<3>(f1)));
+    a = add4(a, ld4(W.b2));
+    const V4 sn = sin4(a);
+    const V4 f2{sn.x / 1.4f + f1.x, sn.y / 1.4f + f1.y, sn.z / 1.4f + f1.z, sn.w / 1.4f + f1.w};
+    const float d = dot(f2, ld4(W.wo));
+    float r = quad_lane<0>(d);
+    r = r + quad_lane<1>(d);
+    r = r + quad_lane<2>(d);
+    r = r + quad_lane<3>(d);
+    return r - 0.16f;
+}
+
+// Ray of one pixel, marched by the four lanes of a quad together.
+KIFS_DEV V3 raymarch_bunny_quad(const FrameParams& P, V3 dir, bool valid, int quad_lane_id, int& steps) {
+    const bool cull = (P.is_heatmap == 0u) && (P.cull_n2 > 0.0f);
+    const bool worth = valid && !(cull && ray_never_inside(P, dir));
+    if (__builtin_amdgcn_ballot_w64(worth) == 0ull) {  // nothing to march: skip the weight loads
+        steps = 0;
+        return P.background_color;
+    }
+    BunnyQuad W;
+    bunny_quad_load(W, quad_lane_id);
+    return raymarch_with(
+        P, dir, valid, steps, [&](V3 q, unsigned long long) { return bunny_sdf_quad(W, q); },
+        [&](V3 q) { return normal_fd(P.epsilon, q, [&](V3 u) { return bunny_sdf_quad(W, u); }); });
 }
 
 }  // namespace kifs

@@ -71,3 +71,21 @@ def test_unknown_primitive_is_all_background(gs, kifs, oracle):
     gs.update_options(u)
     img = gs.render()
     assert (img == img[0, 0]).all() and img[0, 0, 3] == 255
+
+
+@pytest.mark.parametrize("size,band,heatmap", [((77, 45), None, False), ((130, 61), (7, 38), False),
+                                               ((96, 50), (25, 26), False), ((64, 40), None, True)])
+def test_bunny_quad_kernel_ragged_frames_and_bands(size, band, heatmap, gs, kifs, oracle):
+    """The bunny runs four lanes per pixel on quarter tiles (render_bunny_quad_kernel): frames
+    that end inside a tile, bands that start and end inside a quarter tile, heatmap mode (no
+    culls, so every wave loads the weights)."""
+    screen = kifs.ScreenData(*size)
+    cam = kifs.CameraData(origin_distance=2.6, phi=2.1, theta=-0.4)
+    gui = kifs.GuiData(primitive_shape=kifs.PrimitiveShape.Bunny, max_iterations=80, is_heatmap=heatmap,
+                       fractal_color=(90, 220, 140), background_color=(12, 0, 40))
+    y0, y1 = band if band else (0, size[1])
+    want = oracle_frame(oracle, kifs, screen, cam, gui, (100, 10, 10), y0=y0, y1=y1)
+    got = gpu_frame(gs, screen, cam, gui, (100, 10, 10), y0=y0, y1=y1)
+    assert got.shape == want.shape == (y1 - y0, size[0], 4)
+    assert diff_report(got, want)["mismatched_pixels"] == 0
+    assert (want[..., :3] != want[0, 0, :3]).any()

@@ -1,6 +1,8 @@
 #!/bin/bash
-# usage: tools/sweep_pad.sh "<pads>" "<workloads>"
-for pad in $1; do for wl in $2; do
-  KIFS_LDS_PAD=$pad timeout -k 10 200 python bench.py --workload $wl --steps 200 --warmup 20 --cpu-seconds 0 2>/dev/null > /tmp/sweep.json
-  python -c "import json; d=json.load(open('/tmp/sweep.json')); print('pad', $pad, d['config']['workload'], d['value'], 'Mpix/s', d['roofline']['kernel_ms'], 'ms')"
-done; done
+# Residency / feedback sweep of one workload: tools/sweep_pad.sh <workload> [bench flags]
+w=$1; shift
+run() { python bench.py --workload $w --steps 60 --warmup 12 --cpu-seconds 0 "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['kernel_ms'])"; }
+echo "== $w default"; run "$@"
+echo "== $w feedback off"; KIFS_TILE_FEEDBACK=0 run "$@"
+echo "== $w feedback all"; KIFS_TILE_FEEDBACK=2 run "$@"
+for pad in 0 18000 36000 50000 72000 100000; do echo "== $w pad $pad"; KIFS_LDS_PAD=$pad run "$@"; done
