@@ -53,6 +53,15 @@ def parse():
                     help="process-group backend; gloo is only for rehearsing N > 1 on one GPU")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--frames-per-launch", type=int, default=8,
+                    help="frames of the sequence rendered by one launch (kifs_render_batch_async, 1..8); "
+                         "1 = one frame per launch, the lone-frame latency path")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="launches each rank keeps in flight on separate contexts and streams")
+    ap.add_argument("--deliver", default="none", choices=["none", "root"],
+                    help="N > 1, --shard frames: leave every frame in the HBM of the GPU that rendered it "
+                         "(frames are independent units: no exchange step), or ship them to rank 0 by "
+                         "grouped RCCL p2p")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region, compare rank 0's gathered frame with a single-GPU render")
     return ap.parse_args()
@@ -139,9 +148,12 @@ def work_count(w, kernel_s):
             "sample": "whole frame" if stride == 1 else f"every {stride}th row, scaled"}
 
 
-def pmc_traffic(workload_key):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass, if one exists."""
+def pmc_traffic(workload_key, frames_per_launch=1):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass, if one exists (keyed by
+    workload, and workload@B for launches of B frames)."""
     p = ROOT / "profiles" / "pmc_traffic.json"
+    if frames_per_launch > 1:
+        workload_key = f"{workload_key}@{frames_per_launch}"
     try:
         rec = json.loads(p.read_text()).get(workload_key)
         return rec["hbm_bytes_per_launch"] if rec else None
@@ -181,34 +193,60 @@ def main():
     key = args.workload or HEADLINE
     w = WORKLOADS[key]
     W, H = w.screen.width, w.screen.height
-    gs = K.GraphicState(local_rank, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
-    gs.set_iters(*w.iters)
-    if w.extensions:
-        gs.set_extensions(**w.extensions)
-    # Everything (kernel launches, events, the RCCL gather's stream dependencies) runs on
-    # one dedicated non-default stream, made current for the whole benchmark.
-    stream = torch.cuda.Stream(device=device)
+    # F frames in flight: F contexts, each with its own stream, tile tables and output buffer;
+    # step k uses context k % F.  Kernel launches, events and the RCCL gather's stream
+    # dependencies of a step all sit on that context's dedicated non-default stream.
+    F = max(1, args.frames_in_flight)
+    gss, streams = [], []
+    for _ in range(F):
+        g = K.GraphicState(local_rank, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
+        g.set_iters(*w.iters)
+        if w.extensions:
+            g.set_extensions(**w.extensions)
+        g.set_frames_in_flight(F)
+        gss.append(g)
+        streams.append(torch.cuda.Stream(device=device))
+    gs, stream = gss[0], streams[0]
     torch.cuda.set_stream(stream)
-    frames_mode = world > 1 and args.shard == "frames"
-    if frames_mode:
-        bf = FrameStream(W, H, rank, world, device)
+    buffers = F if F >= 2 else 2  # buffer slot k % buffers always belongs to stream k % F
+    bands_mode = world > 1 and args.shard == "bands"
+    frames_mode = world > 1 and not bands_mode
+    B = 1 if bands_mode else max(1, min(args.frames_per_launch, K.MAX_BATCH))
+    cur = [0]  # index of the context / stream of the step being enqueued
+    if not bands_mode:
+        # a step's B frames are stacked in one (B*H, W, 4) buffer
+        bf = FrameStream(W, B * H, rank, world, device, buffers=buffers,
+                         deliver=(args.deliver == "root"))
         rows0 = H
 
-        def render_band(out, frame_index):  # without --orbit every frame is the same view
-            if args.orbit:
-                gs.set_camera(orbit_camera(w, frame_index % max(w.frames, 120)))
-            gs.render_async(out, stream=stream, y0=0, y1=H, encode=args.encode)
+        def render_band(out, step_index):  # without --orbit every frame is the same view
+            g, st = gss[cur[0]], streams[cur[0]]
+            first = step_index * B
+            cams = [orbit_camera(w, (first + i) % max(w.frames, 120)) if args.orbit else w.camera
+                    for i in range(B)]
+            if B == 1:
+                if args.orbit:
+                    g.set_camera(cams[0])
+                g.render_async(out, stream=st, y0=0, y1=H, encode=args.encode)
+            else:
+                g.render_batch_async([out[i * H:(i + 1) * H] for i in range(B)], cams, stream=st,
+                                     y0=0, y1=H, encode=args.encode)
     else:
-        bf = BandFrame(W, H, rank, world, device)
+        bf = BandFrame(W, H, rank, world, device, buffers=buffers)
         rows0 = bf.y1 - bf.y0
 
         orbit_frame = [0]
 
         def render_band(out, y0, y1):
             if args.orbit:
-                gs.set_camera(orbit_camera(w, orbit_frame[0] % max(w.frames, 120)))
+                gss[cur[0]].set_camera(orbit_camera(w, orbit_frame[0] % max(w.frames, 120)))
                 orbit_frame[0] += 1
-            gs.render_async(out, stream=stream, y0=y0, y1=y1, encode=args.encode)
+            gss[cur[0]].render_async(out, stream=streams[cur[0]], y0=y0, y1=y1, encode=args.encode)
+
+    def step(k):
+        cur[0] = k % F
+        with torch.cuda.stream(streams[cur[0]]):
+            bf.step(k, render_band)
 
     def barrier():
         if world > 1:
@@ -218,29 +256,31 @@ def main():
                 dist.barrier()
 
     for k in range(args.warmup):
-        bf.step(k, render_band)
+        step(k)
     bf.wait_all()
     torch.cuda.synchronize()
 
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     # HIP events around the render kernel itself (recorded by the library on the launch stream,
     # one launch in eight): the roofline's "average launch duration"
-    gs.set_profiling(8)  # every 8th launch: an event pair costs a few microseconds
+    for g in gss:
+        g.set_profiling(8)  # every 8th launch: an event pair costs a few microseconds
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record(stream)
     for k in range(args.steps):
-        bf.step(k, render_band)
-    ev1.record(stream)
+        step(args.warmup + k)
     bf.wait_all()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    timed_launches, kernel_mean_ms, kernel_min_ms, kernel_max_ms = gs.profile_read()
-    gs.set_profiling(0)
+    dev_ms = elapsed * 1e3  # this rank's wall time between the two synchronisation points
+    reads = [g.profile_read() for g in gss]
+    timed_launches = sum(r[0] for r in reads)
+    kernel_mean_ms = sum(r[0] * r[1] for r in reads) / max(timed_launches, 1)
+    kernel_min_ms = min((r[2] for r in reads if r[0] > 0), default=0.0)
+    kernel_max_ms = max((r[3] for r in reads if r[0] > 0), default=0.0)
+    for g in gss:
+        g.set_profiling(0)
 
     if world > 1:
         red_dev = device if args.backend == "nccl" else torch.device("cpu")
@@ -256,21 +296,22 @@ def main():
 
     check = None
     if args.check and rank == 0:
-        last = (args.steps - 1) if args.steps > 0 else (args.warmup - 1)
+        last = args.warmup + args.steps - 1
         ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
         gs.render(out=ref, encode=args.encode)
-        if frames_mode:
-            check = all(bool(torch.equal(f, ref)) for f in bf.frames(last))
+        if not bands_mode:  # every frame of the step's batch, from every rank that delivered one
+            check = all(bool(torch.equal(f[i * H:(i + 1) * H], ref))
+                        for f in bf.frames(last) for i in range(B))
         else:
             check = bool(torch.equal(bf.frame(last), ref))
 
     if rank == 0:
-        frames_per_step = world if frames_mode else 1
+        frames_per_step = (world if frames_mode else 1) * B
         mpix = frames_per_step * W * H * args.steps / elapsed / 1e6
         # average duration of the dominant kernel over the timed region (per-launch event pairs);
         # dev_ms / steps additionally contains the inter-launch gaps
         launch_s = (kernel_mean_ms if timed_launches > 0 else dev_ms / args.steps) / 1e3
-        alg_bytes = 4.0 * W * rows0  # 4 B written per pixel, 0 read
+        alg_bytes = 4.0 * W * rows0 * B  # 4 B written per pixel, 0 read; B frames per launch
         achieved = alg_bytes / launch_s / 1e9
         out = {
             "metric": METRIC,
@@ -290,17 +331,22 @@ def main():
                        "normal_iters": w.iters[1], "fold_iters": w.iters[2],
                        "encode": "srgb8" if args.encode else "unorm8",
                        "camera": "orbit, one pose per frame" if args.orbit else "fixed",
-                       "parallelism": "1 GPU, one launch per frame" if world == 1 else
-                       (f"{world} GPUs x whole frames (frame-parallel), one process per GPU, "
-                        "finished frames sent to rank 0 by grouped RCCL p2p" if frames_mode else
-                        f"{world} row bands per frame, one process per GPU, RCCL p2p gather to rank 0")},
+                       "frames_per_launch": B, "launches_in_flight": F,
+                       "parallelism": (
+                           f"1 GPU, {B} frame(s) of the sequence per launch"
+                           + (f", {F} launches in flight" if F > 1 else "") if world == 1 else
+                           (f"{world} GPUs x whole frames (frame-parallel, {B} per launch), one process per GPU, "
+                            + ("finished frames sent to rank 0 by grouped RCCL p2p" if args.deliver == "root"
+                               else "frames stay on the GPU that rendered them (no exchange step)")
+                            if frames_mode else
+                            f"{world} row bands per frame, one process per GPU, RCCL p2p gather to rank 0"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": pmc_traffic(key) if world == 1 else None,
+                         "traffic": pmc_traffic(key, B) if world == 1 else None,
                          "kernel": "render_kernel", "kernel_ms": round(launch_s * 1e3, 5),
                          "kernel_ms_min": round(kernel_min_ms, 5), "kernel_ms_max": round(kernel_max_ms, 5),
                          "launches_timed": timed_launches,
-                         "stream_ms_per_step": round(dev_ms / args.steps, 5),
+                         "concurrent_launches": F,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
             "per_rank_kernel_ms": [round(x, 5) for x in per_rank_ms],
         }
@@ -308,10 +354,11 @@ def main():
             out["gathered_frame_equals_single_gpu_frame"] = check
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
-            out["roofline"]["secondary"] = work_count(w, launch_s)
+            out["roofline"]["secondary"] = work_count(w, launch_s / B)
         print(json.dumps(out), flush=True)
 
-    gs.close()
+    for g in gss:
+        g.close()
     if world > 1:
         dist.destroy_process_group()
 

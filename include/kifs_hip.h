@@ -162,6 +162,19 @@ int kifs_render(kifs_ctx* ctx, uint8_t* out_rgba8, size_t pitch_bytes, int y0, i
 int kifs_render_async(kifs_ctx* ctx, void* hip_stream, uint8_t* dev_out_rgba8,
                       size_t pitch_bytes, int y0, int y1, int encode);
 
+/* A batch of frames in one launch: frame i is rendered with cameras[i] (the context's screen,
+ * options, iteration counts and extensions; the context's own camera is neither used nor
+ * changed) into dev_outs[i], same pitch / band / encoding for all.  1 <= count <= KIFS_MAX_BATCH.
+ * This is the throughput path for sequences of independent frames (the frames of an orbit,
+ * cf. rotate_camera graphics.rs:280-302): one frame of these scenes keeps most of the device
+ * idle -- its run time is the critical path of a few long rays -- and the workgroups of a batch
+ * are interleaved frame by frame, so the long rays of all its frames march side by side.
+ * Every frame is bit-identical to the same frame rendered alone. */
+#define KIFS_MAX_BATCH 8
+int kifs_render_batch_async(kifs_ctx* ctx, void* hip_stream, int count,
+                            const KifsCameraUniform* cameras, uint8_t* const* dev_outs_rgba8,
+                            size_t pitch_bytes, int y0, int y1, int encode);
+
 /* Contiguous row-band partition used for multi-GPU frames: rank r
  * of `world` owns rows [y0, y1); bands differ by at most one row. */
 int kifs_band_range(int height, int rank, int world, int* y0, int* y1);
@@ -203,6 +216,15 @@ double kifs_last_kernel_ms(kifs_ctx* ctx);
  * minimum and maximum kernel duration in ms, and clears the ring. */
 int kifs_set_profiling(kifs_ctx* ctx, int enable);
 int kifs_profile_read(kifs_ctx* ctx, int* launches, double* mean_ms, double* min_ms, double* max_ms);
+
+/* Scheduling hint.  n = how many frames the caller keeps in flight on this device at once
+ * (several contexts, one stream each; the reference queues up to
+ * desired_maximum_frame_latency = 2 frames, render.rs:108).  With n = 1 (default) a launch is
+ * tuned for the latency of a lone frame: frames whose run time is the critical path of a few
+ * long rays cap their own residency so that those rays have a SIMD to themselves.  With n > 1
+ * the device is shared on purpose and the cap is dropped (throughput over latency).  Pixels do
+ * not depend on it.  Returns KIFS_ERR_BAD_ARG for n < 1. */
+int kifs_set_frames_in_flight(kifs_ctx* ctx, int n);
 
 /* Blocks until everything the context enqueued on its own stream is done. */
 int kifs_synchronize(kifs_ctx* ctx);

@@ -75,6 +75,8 @@ SIGNATURES = {
     "kifs_render": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "kifs_render_async": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                     C.c_int]),
+    "kifs_render_batch_async": (C.c_int, [_ctx, C.c_void_p, C.c_int, _P(CameraUniform),
+                                          _P(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "kifs_band_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "kifs_multi_create": (_ctx, [_P(C.c_int), C.c_int, _P(C.c_int)]),
     "kifs_multi_destroy": (None, [_ctx]),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "kifs_last_kernel_ms": (C.c_double, [_ctx]),
     "kifs_synchronize": (C.c_int, [_ctx]),
     "kifs_set_profiling": (C.c_int, [_ctx, C.c_int]),
+    "kifs_set_frames_in_flight": (C.c_int, [_ctx, C.c_int]),
     "kifs_profile_read": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "kifs_strerror": (C.c_char_p, [C.c_int]),
     "kifs_abi_version": (C.c_int, []),

@@ -137,9 +137,12 @@ class FrameStream:
     BandFrame: the transfers of step k overlap the rendering of step k+1."""
 
     def __init__(self, width: int, height: int, rank: int, world: int, device,
-                 root: int = 0, buffers: int = 2, group=None):
+                 root: int = 0, buffers: int = 2, group=None, deliver: bool = True):
+        """deliver=False: frames stay in the HBM of the rank that rendered them (no exchange
+        step at all: frames are independent units); frames(k) then holds only the root's own."""
         if width <= 0 or height <= 0 or world <= 0 or not (0 <= rank < world):
             raise ValueError("FrameStream: bad geometry")
+        self.deliver = deliver and world > 1
         self.width, self.height = width, height
         self.rank, self.world, self.root = rank, world, root
         self.device = torch.device(device)
@@ -149,14 +152,14 @@ class FrameStream:
         if rank == root:
             # slot[b][r] = frame rendered by rank r in a step using buffer b
             self._slots = [[torch.zeros(shape, dtype=torch.uint8, device=self.device)
-                            for _ in range(world)] for _ in range(buffers)]
-            self._mine = [self._slots[b][root] for b in range(buffers)]
+                            for _ in range(world if self.deliver else 1)] for _ in range(buffers)]
+            self._mine = [self._slots[b][root if self.deliver else 0] for b in range(buffers)]
         else:
             self._slots = None
             self._mine = [torch.zeros(shape, dtype=torch.uint8, device=self.device)
                           for _ in range(buffers)]
         self._works: List[Optional[list]] = [None] * buffers
-        self._staged = (world > 1 and self.device.type == "cuda"
+        self._staged = (self.deliver and self.device.type == "cuda"
                         and dist.get_backend(group) == "gloo")  # rehearsal only, see BandFrame
         if self._staged:
             n = world if rank == root else 1
@@ -174,7 +177,7 @@ class FrameStream:
         return self._slots[k % self.buffers] if self.rank == self.root else None
 
     def gather_async(self, k: int):
-        if self.world == 1:
+        if not self.deliver:
             return
         slot = k % self.buffers
         ops = []

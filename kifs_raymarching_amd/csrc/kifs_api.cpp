@@ -63,6 +63,7 @@ struct kifs_ctx {
     bool have_screen = false, have_camera = false, have_options = false;
     int sdf_iters = 100, normal_iters = 10, fold_iters = 10;  // julia.wgsl:2-3, kifs.wgsl:72
     KifsExtensions ext{};  // all zero: the reference's behaviour
+    int frames_in_flight = 1;  // kifs_set_frames_in_flight
     // per-launch profiling ring (kifs_set_profiling)
     bool profiling = false;
     int prof_every = 1;      // time every n-th launch
@@ -326,20 +327,39 @@ int residency_for(const kifs::FrameParams& P, uint32_t group, int frame_height, 
     return 0;
 }
 
-int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int y0, int y1,
-            int encode) {
+// One launch: `count` frames (count == 1: the context's camera; count > 1: cameras[i] -> outs[i])
+// sharing everything else.
+int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUniform* cameras,
+                  uint8_t* const* outs, size_t pitch, int y0, int y1, int encode) {
     hip_ok(hipGetLastError(), "stale error before enqueue");
-    if (!c->have_screen || !c->have_camera || !c->have_options) return KIFS_ERR_UNCONFIGURED;
-    if (!dev_out) return KIFS_ERR_BAD_ARG;
+    if (!c->have_screen || !c->have_options || (!c->have_camera && !cameras)) return KIFS_ERR_UNCONFIGURED;
+    if (count < 1 || count > kifs::MAX_BATCH || !outs) return KIFS_ERR_BAD_ARG;
+    for (int i = 0; i < count; ++i)
+        if (!outs[i] || (reinterpret_cast<uintptr_t>(outs[i]) & 3u) != 0) return KIFS_ERR_BAD_ARG;
+    uint8_t* const dev_out = outs[0];
     if (encode != KIFS_ENCODE_UNORM && encode != KIFS_ENCODE_SRGB) return KIFS_ERR_BAD_ARG;
-    kifs::FrameParams P;
+    kifs::BatchParams B;
+    kifs::FrameParams& P = B.frame;
     int st = fill_params(c, &P);
     if (st != KIFS_OK) return st;
+    B.count = count;
+    for (int i = 0; i < count; ++i) {
+        const KifsCameraUniform& cam = cameras ? cameras[i] : c->camera;
+        kifs::BatchView& v = B.view[i];
+        v.origin = {cam.origin[0], cam.origin[1], cam.origin[2]};
+        v.m0 = {cam.matrix[0][0], cam.matrix[0][1], cam.matrix[0][2]};
+        v.m1 = {cam.matrix[1][0], cam.matrix[1][1], cam.matrix[1][2]};
+        v.m2 = {cam.matrix[2][0], cam.matrix[2][1], cam.matrix[2][2]};
+        v.out = reinterpret_cast<uint32_t*>(outs[i]);
+    }
+    P.origin = B.view[0].origin;
+    P.m0 = B.view[0].m0;
+    P.m1 = B.view[0].m1;
+    P.m2 = B.view[0].m2;
     const int h = P.y1;
     if (y0 < 0 || y1 > h || y0 > y1) return KIFS_ERR_BAD_ARG;
     if (pitch < size_t(P.width) * 4 || (pitch & 3u) != 0 || (pitch >> 2) > 0xffffffffull)
         return KIFS_ERR_BAD_SIZE;
-    if ((reinterpret_cast<uintptr_t>(dev_out) & 3u) != 0) return KIFS_ERR_BAD_ARG;
     P.y0 = y0;
     P.y1 = y1;
     P.encode = encode;
@@ -380,7 +400,29 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
             return KIFS_ERR_RUNTIME;
     }
     if (use_feedback) tt->last_stream = stream;
-    const uint64_t k = use_feedback ? tt->launches % FEEDBACK_PERIOD : 0;
+    // a batch is launched with the sort in its own stream and refreshes every other launch: its
+    // launches are long, its views move (an orbit), and the device is full anyway
+    const uint64_t period = count > 1 ? 2 : FEEDBACK_PERIOD;
+    const uint64_t k = use_feedback ? tt->launches % period : 0;
+    // With several frames in flight (several contexts and streams on one device) the sort runs
+    // in the launch stream itself: streams share a handful of hardware queues, and an event wait
+    // parked in a queue also holds up whatever other context's launches sit behind it (measured:
+    // two contexts fell back to running one after the other).  The 10 us then hide behind the
+    // other frames' kernels.  A lone frame keeps the side stream: there nothing else can.
+    const bool inline_sort = c->frames_in_flight > 1 || count > 1;
+    if (use_feedback && inline_sort && tt->sort_pending) {
+        // a side-stream sort from earlier lone launches still owns d_order_alt: take its result first
+        if (!hip_ok(hipStreamWaitEvent(stream, tt->sorted, 0), "wait(sorted)")) return KIFS_ERR_RUNTIME;
+        std::swap(tt->d_order, tt->d_order_alt);
+        tt->sort_pending = false;
+    }
+    if (use_feedback && inline_sort && k == 1) {
+        const uint32_t tiles_x = uint32_t((P.width + kifs::TILE_W - 1) / kifs::TILE_W);
+        if (!hip_ok(kifs::launch_tile_order(tt->d_cost[0], tt->d_order_alt, tt->count, tiles_x, stream),
+                    "tile_order_kernel launch"))
+            return KIFS_ERR_RUNTIME;
+        std::swap(tt->d_order, tt->d_order_alt);  // stream order: the sort precedes this launch
+    }
     if (use_feedback && k == 2 && tt->sort_pending) {  // adopt the order the side stream prepared
         if (!hip_ok(hipStreamWaitEvent(stream, tt->sorted, 0), "wait(sorted)")) return KIFS_ERR_RUNTIME;
         std::swap(tt->d_order, tt->d_order_alt);
@@ -390,11 +432,13 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
     P.tile_order = tt->d_order;
     P.tile_count = tt->count;
     P.tile_cost = record_costs ? tt->d_cost[0] : nullptr;
-    P.workgroups_per_cu = residency_for(P, c->options.fractal_group_id, h, tt->count);
+    // the residency cap serves a lone frame's latency; concurrent frames want every slot
+    P.workgroups_per_cu = (c->frames_in_flight > 1 || count > 1)
+                              ? 0 : residency_for(P, c->options.fractal_group_id, h, tt->count);
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
     const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
     if (timed && !hip_ok(hipEventRecord(c->prof_a[pslot], stream), "record(profile start)")) return KIFS_ERR_RUNTIME;
-    hipError_t e = kifs::launch_render(P, c->options.fractal_group_id, c->options.primitive_id,
+    hipError_t e = kifs::launch_render(B, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
     if (!hip_ok(e, "render_kernel launch")) return KIFS_ERR_RUNTIME;
     if (timed) {
@@ -407,6 +451,7 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
         return KIFS_OK;
     }
     tt->launches += 1;
+    if (inline_sort) return KIFS_OK;
     if (record_costs) {
         // Launch k = 0 of the period wrote d_cost[0].  The previous sort (period before) read it
         // and finished before that period's launch 2 started, i.e. long ago on this timeline.
@@ -426,6 +471,13 @@ int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int
         tt->sort_pending = true;
     }
     return KIFS_OK;
+}
+
+int enqueue(kifs_ctx* c, hipStream_t stream, uint8_t* dev_out, size_t pitch, int y0, int y1,
+            int encode) {
+    if (!c->have_camera) return KIFS_ERR_UNCONFIGURED;
+    if (!dev_out) return KIFS_ERR_BAD_ARG;
+    return enqueue_batch(c, stream, 1, nullptr, &dev_out, pitch, y0, y1, encode);
 }
 
 }  // namespace
@@ -560,6 +612,16 @@ int kifs_render_async(kifs_ctx* c, void* hip_stream, uint8_t* dev_out, size_t pi
     return enqueue(c, s, dev_out, pitch, y0, y1, encode);
 }
 
+int kifs_render_batch_async(kifs_ctx* c, void* hip_stream, int count, const KifsCameraUniform* cameras,
+                            uint8_t* const* dev_outs, size_t pitch, int y0, int y1, int encode) {
+    if (!c || !cameras || !dev_outs) return KIFS_ERR_BAD_ARG;
+    static_assert(KIFS_MAX_BATCH == kifs::MAX_BATCH, "header and kernels agree on the batch limit");
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return enqueue_batch(c, s, count, cameras, dev_outs, pitch, y0, y1, encode);
+}
+
 int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int encode) {
     if (!c || !out) return KIFS_ERR_BAD_ARG;
     DeviceGuard g(c->device);
@@ -603,6 +665,12 @@ int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int enc
 }
 
 double kifs_last_kernel_ms(kifs_ctx* c) { return c ? c->last_ms : -1.0; }
+
+int kifs_set_frames_in_flight(kifs_ctx* c, int n) {
+    if (!c || n < 1) return KIFS_ERR_BAD_ARG;
+    c->frames_in_flight = n;
+    return KIFS_OK;
+}
 
 int kifs_set_profiling(kifs_ctx* c, int enable) {
     if (!c) return KIFS_ERR_BAD_ARG;

@@ -7,10 +7,10 @@
 
 namespace kifs {
 
-hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitive,
+hipError_t launch_render(const BatchParams& B, uint32_t group, uint32_t primitive,
                          hipStream_t stream);
-// Device-side counting sort: order[] = tile ids (x | y << 16) by descending cost[].
-hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t tile_count,
+// Device-side counting sort: order[] = tile ids (x | y << 16) by descending cost[]; clears cost[].
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_count,
                              uint32_t tiles_x, hipStream_t stream);
 hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,
                               const float* pts, int n, float* sdf, float* nrm,

@@ -29,12 +29,32 @@ namespace kifs {
 
 constexpr int BLOCK = TILE_W * TILE_H;  // 256 threads = 4 waves
 
+// Frame `view` of the batch: the common parameters with that view's camera and destination.
+// Workgroup b of a launch works on view b % count and takes entry b / count of the tile order,
+// so the expensive tiles of every frame of the batch start at t = 0.
+__device__ __forceinline__ FrameParams batch_frame(const BatchParams& B, uint32_t view) {
+    FrameParams P = B.frame;
+    if (B.count > 1) {  // uniform; a batch of one carries its view in B.frame already
+        const BatchView& v = B.view[view];
+        P.origin = v.origin;
+        P.m0 = v.m0;
+        P.m1 = v.m1;
+        P.m2 = v.m2;
+        P.out = v.out;
+    }
+    return P;
+}
+
 template <int GROUP, int PRIM>
-__global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
+__global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
     __shared__ float s_srgb[256];
     __shared__ uint32_t s_tile[TILE_H][TILE_W];
     __shared__ int s_steps[BLOCK / 64];
 
+    const uint32_t batch = uint32_t(B.count);
+    const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
+    const uint32_t slot = batch > 1 ? blockIdx.x / batch : blockIdx.x;
+    const FrameParams P = batch_frame(B, view);
     const int tid = threadIdx.x;
     const bool srgb = (P.encode == 1);
     if (srgb) s_srgb[tid] = P.srgb_table[tid];
@@ -43,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
     const int wave = tid >> 6, lane = tid & 63;
     const int lx = (wave << 3) | (lane & 7);
     const int ly = lane >> 3;
-    const uint32_t tile = P.tile_order[blockIdx.x];  // scalar load: uniform per workgroup
+    const uint32_t tile = P.tile_order[slot];  // scalar load: uniform per workgroup
     const int tile_x = int(tile & 0xffffu) * TILE_W;
     const int tile_y = int(tile >> 16) * TILE_H;     // row offset within the band
     const int x = tile_x + lx;
@@ -73,7 +93,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
     if (tid == 0 && feedback) {
         const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
         const int m = max(max(s_steps[0], s_steps[1]), max(s_steps[2], s_steps[3]));
-        P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)] = uint32_t(m);
+        uint32_t* cost = &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)];
+        if (batch > 1) atomicMax(cost, uint32_t(m));  // the batch's views share the table (the sort clears it)
+        else *cost = uint32_t(m);
     }
     uint32_t r, g, b;
     if (srgb) {
@@ -100,10 +122,14 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const FrameParams P) {
 // workgroup renders a quarter of a 32 x 8 tile, rows [2 sub, 2 sub + 2); wave w owns the 8 x 2
 // pixels at columns [8w, 8w + 8), lane -> pixel lane >> 2, column group lane & 3.  Same tile
 // order table, same LDS-staged store (two full 128-byte rows per workgroup).
-__global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const FrameParams P) {
+__global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const BatchParams B) {
     __shared__ float s_srgb[256];
     __shared__ uint32_t s_tile[2][TILE_W];
 
+    const uint32_t batch = uint32_t(B.count);
+    const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
+    const uint32_t block = batch > 1 ? blockIdx.x / batch : blockIdx.x;
+    const FrameParams P = batch_frame(B, view);
     const int tid = threadIdx.x;
     const bool srgb = (P.encode == 1);
     if (srgb) s_srgb[tid] = P.srgb_table[tid];
@@ -112,8 +138,8 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const FramePar
     const int pixel = lane >> 2, group = lane & 3;
     const int lx = (wave << 3) | (pixel & 7);
     const int ly = pixel >> 3;
-    const uint32_t tile = P.tile_order[blockIdx.x >> 2];
-    const int sub = int(blockIdx.x & 3u);
+    const uint32_t tile = P.tile_order[block >> 2];
+    const int sub = int(block & 3u);
     const int tile_x = int(tile & 0xffffu) * TILE_W;
     const int tile_y = int(tile >> 16) * TILE_H + 2 * sub;  // row offset within the band
     const int x = tile_x + lx;
@@ -169,7 +195,8 @@ static unsigned residency_pad_bytes(int workgroups_per_cu) {
 // frame by fractal_group (graphics.rs:310-321); the KIFS shader then switches on
 // primitive_id per SDF call (kifs.wgsl:139-155).  Here both are template parameters.
 template <int GROUP, int PRIM>
-static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
+static hipError_t launch_variant(const BatchParams& B, hipStream_t stream) {
+    const FrameParams& P = B.frame;
     const unsigned pad = residency_pad_bytes(P.workgroups_per_cu);
     if (pad > 48 * 1024) {
         // beyond the default dynamic-LDS limit: opt in once per kernel AND per device (the
@@ -184,30 +211,35 @@ static hipError_t launch_variant(const FrameParams& P, hipStream_t stream) {
             if (dev >= 0 && dev < 64) opted_in[dev] = true;
         }
     }
-    hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), dim3(P.tile_count), dim3(BLOCK), pad, stream, P);
+    hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), dim3(P.tile_count * uint32_t(B.count)), dim3(BLOCK), pad, stream, B);
     return hipGetLastError();
 }
 
-static hipError_t launch_bunny_quad(const FrameParams& P, hipStream_t stream) {
-    hipLaunchKernelGGL(render_bunny_quad_kernel, dim3(P.tile_count * 4u), dim3(BLOCK), 0, stream, P);
+static hipError_t launch_bunny_quad(const BatchParams& B, hipStream_t stream) {
+    hipLaunchKernelGGL(render_bunny_quad_kernel, dim3(B.frame.tile_count * 4u * uint32_t(B.count)), dim3(BLOCK), 0,
+                       stream, B);
     return hipGetLastError();
 }
 
-hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitive,
+hipError_t launch_render(const BatchParams& B, uint32_t group, uint32_t primitive,
                          hipStream_t stream) {
+    const FrameParams& P = B.frame;
     if (P.y1 <= P.y0 || P.width <= 0 || P.tile_count == 0) return hipSuccess;
+    if (B.count < 1 || B.count > MAX_BATCH) return hipErrorInvalidValue;
     switch (group) {
-    case GROUP_JULIA: return launch_variant<GROUP_JULIA, 0>(P, stream);
-    case GROUP_GENJULIA: return launch_variant<GROUP_GENJULIA, 0>(P, stream);
+    case GROUP_JULIA:  // two builds of the long-ray loop, see KIFS_DIVSQRT_ORDINARY in kifs_scene.hpp
+        return P.sdf_iters <= 24 ? launch_variant<GROUP_JULIA, 1>(B, stream)
+                                 : launch_variant<GROUP_JULIA, 0>(B, stream);
+    case GROUP_GENJULIA: return launch_variant<GROUP_GENJULIA, 0>(B, stream);
     case GROUP_KIFS:
         switch (primitive) {
-        case PRIM_SPHERE: return launch_variant<GROUP_KIFS, PRIM_SPHERE>(P, stream);
-        case PRIM_CYLINDER: return launch_variant<GROUP_KIFS, PRIM_CYLINDER>(P, stream);
-        case PRIM_BOX: return launch_variant<GROUP_KIFS, PRIM_BOX>(P, stream);
-        case PRIM_TORUS: return launch_variant<GROUP_KIFS, PRIM_TORUS>(P, stream);
-        case PRIM_SIERPINSKI: return launch_variant<GROUP_KIFS, PRIM_SIERPINSKI>(P, stream);
-        case PRIM_BUNNY: return launch_bunny_quad(P, stream);
-        default: return launch_variant<GROUP_KIFS, PRIM_OTHER>(P, stream);  // kifs.wgsl:154
+        case PRIM_SPHERE: return launch_variant<GROUP_KIFS, PRIM_SPHERE>(B, stream);
+        case PRIM_CYLINDER: return launch_variant<GROUP_KIFS, PRIM_CYLINDER>(B, stream);
+        case PRIM_BOX: return launch_variant<GROUP_KIFS, PRIM_BOX>(B, stream);
+        case PRIM_TORUS: return launch_variant<GROUP_KIFS, PRIM_TORUS>(B, stream);
+        case PRIM_SIERPINSKI: return launch_variant<GROUP_KIFS, PRIM_SIERPINSKI>(B, stream);
+        case PRIM_BUNNY: return launch_bunny_quad(B, stream);
+        default: return launch_variant<GROUP_KIFS, PRIM_OTHER>(B, stream);  // kifs.wgsl:154
         }
     default: return hipErrorInvalidValue;
     }
@@ -217,7 +249,7 @@ hipError_t launch_render(const FrameParams& P, uint32_t group, uint32_t primitiv
 // One 1024-thread workgroup: histogram of clamped costs (bin 0 = heaviest), exclusive scan,
 // scatter.  Whatever the cost values are, the result is a permutation of the tile ids, so a
 // stale or garbage cost table can only cost speed, never pixels.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost,
+__global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* __restrict__ cost,
                                                           uint32_t* __restrict__ order, uint32_t n,
                                                           uint32_t tiles_x) {
     constexpr uint32_t BINS = 1024, LAST = BINS - 1;  // bin 0 = heaviest, LAST = cost 0
@@ -264,11 +296,14 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
         uint32_t pos;
         if (zero) pos = zbase + uint32_t(__builtin_popcountll(zmask & ((1ull << lane) - 1ull)));
         else if (live) pos = atomicAdd(&bins[bin], 1u);
-        if (live) order[pos] = (i % tiles_x) | ((i / tiles_x) << 16);
+        if (live) {
+            order[pos] = (i % tiles_x) | ((i / tiles_x) << 16);
+            cost[i] = 0;  // ready for the next recording launch (batches accumulate with atomicMax)
+        }
     }
 }
 
-hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t tile_count,
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_count,
                              uint32_t tiles_x, hipStream_t stream) {
     if (tile_count == 0) return hipSuccess;
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, tile_count, tiles_x);

@@ -56,4 +56,18 @@ struct FrameParams {
     int workgroups_per_cu;
 };
 
+// A launch renders a batch of up to MAX_BATCH frames that share screen, options and tile
+// order and differ in camera and destination (the frames of an orbit).  One frame's run time
+// is the critical path of a few long rays with most SIMDs idle; a batch fills them.
+constexpr int MAX_BATCH = 8;
+struct BatchView {
+    V3 origin, m0, m1, m2;  // CameraUniform of this frame
+    uint32_t* out;          // first row of its band
+};
+struct BatchParams {
+    FrameParams frame;      // everything common; its camera fields and `out` are those of view 0
+    int count;              // 1..MAX_BATCH
+    BatchView view[MAX_BATCH];
+};
+
 }  // namespace kifs

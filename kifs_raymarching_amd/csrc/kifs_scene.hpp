@@ -328,6 +328,7 @@ KIFS_DEV bool sierpinski_folds(const FrameParams& P, V3& p, float& n2, float& sc
         "s_and_b64 exec, exec, %[lanes]\n"   // lanes whose result nobody reads do not fold
         "v_cmpx_gt_f32_e32 vcc, %[stop], v43\n"
         "s_cbranch_execz 1f\n"
+        ".p2align 6\n"   // the back edge's target on a 64-byte line (a lone wave refetches after a taken branch)
         "0:\n"
         KIFS_FOLD_STEP
         "s_sub_u32 %[n], %[n], 1\n"
@@ -533,6 +534,82 @@ KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit, Sdf
     "v_pk_add_f32 v[44:45], v[44:45], %[c0x]\n"                                               \
     "v_cmpx_nlt_f32 vcc, %[maxd], v44\n" /* exec &= !(|q|^2 > max_distance): escaped lanes freeze */
 
+// quot = |q|^2 / dqs and root = sqrt(quot), both correctly rounded, any operands: the sequences
+// hipcc emits (v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup; v_sqrt + one-ulp fixup
+// with the 2^32 pre-scaling for tiny arguments), with their wait states.  v44 = |q|^2, v53 = dqs,
+// v55 = lg in; v54 = 0.25 lg and v60 = root out.
+#define KIFS_DIVSQRT_FULL \
+    /* ---- quot = |q|^2 / dqs, correctly rounded */ \
+    "v_div_scale_f32 v60, s[82:83], v53, v53, v44\n" \
+    "v_div_scale_f32 v61, vcc, v44, v53, v44\n" \
+    "v_rcp_f32_e32 v62, v60\n" \
+    "v_mul_f32_e32 v54, 0x3e800000, v55\n"  /* 0.25 * lg */ \
+    "v_fma_f32 v63, -v60, v62, 1.0\n" \
+    "v_fmac_f32_e32 v62, v63, v62\n" \
+    "v_mul_f32_e32 v63, v61, v62\n" \
+    "v_fma_f32 v55, -v60, v63, v61\n" \
+    "v_fmac_f32_e32 v63, v55, v62\n" \
+    "v_fma_f32 v60, -v60, v63, v61\n" \
+    "v_div_fmas_f32 v60, v60, v62, v63\n" \
+    "v_div_fixup_f32 v60, v60, v53, v44\n" \
+    /* ---- root = sqrt(quot), correctly rounded */ \
+    "v_mul_f32_e32 v61, 0x4f800000, v60\n" \
+    "v_cmp_gt_f32_e32 vcc, 0x0f800000, v60\n"  /* below 2^-96: work on quot * 2^32 */ \
+    "s_nop 1\n" \
+    "v_cndmask_b32_e32 v60, v60, v61, vcc\n" \
+    "v_sqrt_f32_e32 v61, v60\n" \
+    "s_nop 0\n" \
+    "v_add_u32_e32 v62, -1, v61\n"  /* candidates one ulp either side */ \
+    "v_add_u32_e32 v63, 1, v61\n" \
+    "v_fma_f32 v52, -v62, v61, v60\n" \
+    "v_fma_f32 v56, -v63, v61, v60\n" \
+    "v_cmp_ge_f32_e64 s[80:81], 0, v52\n" \
+    "v_cmp_lt_f32_e64 s[82:83], 0, v56\n" \
+    "s_nop 0\n" \
+    "v_cndmask_b32_e64 v62, v61, v62, s[80:81]\n" \
+    "v_cndmask_b32_e64 v61, v62, v63, s[82:83]\n" \
+    "v_mul_f32_e32 v62, 0x37800000, v61\n" \
+    "v_cndmask_b32_e32 v61, v61, v62, vcc\n"  /* undo the 2^32 scaling */ \
+    "v_cmp_class_f32_e64 vcc, v60, s94\n"  /* sqrt(+-0) = +-0, sqrt(inf) = inf */ \
+    "s_nop 1\n" \
+    "v_cndmask_b32_e32 v60, v61, v60, vcc\n"
+
+// The same two results when both operands are ordinary -- |q|^2 and dqs within [2^-10, 2^84): the
+// exponents differ by at most 94, so v_div_scale would scale nothing (it does from 96), v_div_fmas
+// is a plain fma, v_div_fixup passes the quotient through, and the quotient (> 2^-95) needs
+// neither the 2^32 pre-scaling (below 2^-96) nor the zero / infinity patch of the square root: the same Newton and fixup arithmetic, nine instructions and four wait
+// states shorter.  A wave with a lane outside the range runs KIFS_DIVSQRT_FULL out of line.
+// Used when sdf_iters is small: after ~25 iterations dqs of a bounded orbit leaves the range.
+#define KIFS_DIVSQRT_ORDINARY \
+    "v_subrev_u32_e32 v60, 0x3a800000, v44\n"   /* bits - bits(2^-10) */ \
+    "v_subrev_u32_e32 v61, 0x3a800000, v53\n" \
+    "v_max_u32_e32 v60, v60, v61\n" \
+    "v_cmp_gt_u32_e32 vcc, 0x2f000000, v60\n"   /* both below 2^84 (and not negative / NaN) */ \
+    "s_xor_b64 vcc, vcc, exec\n" \
+    "s_cbranch_scc1 46f\n" \
+    "v_rcp_f32_e32 v62, v53\n" \
+    "v_mul_f32_e32 v54, 0x3e800000, v55\n"      /* 0.25 * lg */ \
+    "v_fma_f32 v63, -v53, v62, 1.0\n" \
+    "v_fmac_f32_e32 v62, v63, v62\n" \
+    "v_mul_f32_e32 v63, v44, v62\n" \
+    "v_fma_f32 v55, -v53, v63, v44\n" \
+    "v_fmac_f32_e32 v63, v55, v62\n" \
+    "v_fma_f32 v60, -v53, v63, v44\n" \
+    "v_fma_f32 v60, v60, v62, v63\n" \
+    "v_sqrt_f32_e32 v61, v60\n" \
+    "s_nop 0\n" \
+    "v_add_u32_e32 v62, -1, v61\n"               /* candidates one ulp either side */ \
+    "v_add_u32_e32 v63, 1, v61\n" \
+    "v_fma_f32 v52, -v62, v61, v60\n" \
+    "v_fma_f32 v56, -v63, v61, v60\n" \
+    "v_cmp_ge_f32_e64 s[80:81], 0, v52\n" \
+    "v_cmp_lt_f32_e64 s[82:83], 0, v56\n" \
+    "s_nop 0\n" \
+    "v_cndmask_b32_e64 v62, v61, v62, s[80:81]\n" \
+    "v_cndmask_b32_e64 v60, v62, v63, s[82:83]\n" \
+    "47:\n"
+
+template <bool SHORT_DIVSQRT>
 KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit,
                                bool& marching, int& trips, int& outside_steps) {
     F2 pyz{p.y, p.z}, px1{p.x, 1.0f}, tdx{t, dir.x};
@@ -541,199 +618,19 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
     const float c1 = -1.1514610310E-1f;  // second log coefficient, needed in a VGPR
     const unsigned long long lanes = __builtin_amdgcn_ballot_w64(marching);
     unsigned long long hit_mask = 0, live_out;
-    asm volatile(
-        "s_setprio 3\n"   // after the culls only rays that reach the fractal get here: issue them first
-        "s_mov_b64 s[84:85], exec\n"
-        "s_and_b64 exec, exec, %[lanes]\n"
-        "s_mov_b32 s88, 2.0\n"
-        "s_mov_b32 s89, 4.0\n"
-        "s_mov_b32 s90, 2.0\n"
-        "s_mov_b32 s91, 1.0\n"
-        "s_mov_b32 s92, 0x7fffff\n"
-        "s_movk_i32 s93, 0x100\n"                              // class mask: +normal
-        "s_movk_i32 s94, 0x260\n"                              // class mask: -0, +0, +inf
-        "v_cmp_lt_f32_e64 s[74:75], 0, %[cullv]\n"            // all ones when the culls are enabled
-        // ------------------------------------------------------------------ one march step
-        "10:\n"
-        "v_mul_f32_e32 v52, v32, v32\n"                       // dot(p,p): x*x, +y*y, +z*z
-        "v_fma_f32 v52, v30, v30, v52\n"
-        "v_fma_f32 v52, v31, v31, v52\n"
-        "v_cmp_lt_f32 vcc, %[bound], v52\n"                   // length(p) > 2 + epsilon ?
-        "s_mov_b64 s[78:79], vcc\n"                           // lanes outside the sphere (usually none)
-        "s_andn2_b64 exec, exec, vcc\n"                       // lanes inside run the orbit
-        "s_cbranch_execz 40f\n"
-        "v_pk_mul_f32 v[46:47], v[32:33], s[90:91]\n"         // T = [2 x_0, 1]
-        "v_mov_b64 v[40:41], v[30:31]\n"                      // YZ = [y_0, z_0]
-        "v_mov_b64 v[42:43], v[38:39]\n"                      // WD = [0.1, 1]
-        "v_pk_mul_f32 v[48:49], v[40:41], v[40:41]\n"         // squares of q_0 -> Q = [|q_0|^2, x_1]
-        "v_pk_add_f32 v[50:51], v[48:49], v[48:49] op_sel:[0,1] op_sel_hi:[0,1]\n"
-        "v_pk_fma_f32 v[48:49], v[42:43], v[42:43], v[50:51] op_sel_hi:[0,0,1]\n"
-        "v_pk_fma_f32 v[44:45], v[32:33], v[32:33], v[48:49] op_sel_hi:[0,0,1] neg_hi:[0,0,1]\n"
-        "v_pk_add_f32 v[44:45], v[44:45], %[c0x]\n"
-        "s_mov_b64 s[86:87], exec\n"
-        "s_mov_b32 s96, %[blocks]\n"
-        "s_cmp_lg_u32 %[rem], 0\n"
-        "s_cbranch_scc1 30f\n"                                // trip count not a multiple of 6 (out of line)
-        "12:\n"
-        "s_cmp_eq_u32 s96, 0\n"
-        "s_cbranch_scc1 14f\n"
-        "13:\n"
-        KIFS_FAST_TRIP KIFS_FAST_TRIP KIFS_FAST_TRIP
-        "s_cbranch_execz 14f\n"
-        KIFS_FAST_TRIP KIFS_FAST_TRIP KIFS_FAST_TRIP
-        "s_cbranch_execz 14f\n"
-        "s_sub_u32 s96, s96, 1\n"
-        "s_cmp_lg_u32 s96, 0\n"
-        "s_cbranch_scc1 13b\n"
-        "14:\n"
-        "s_mov_b64 exec, s[86:87]\n"
-        // |q|^2 must be a positive normal number for the short log; otherwise hand the step back
-        "v_cmp_class_f32_e64 vcc, v44, s93\n"
-        "s_xor_b64 vcc, vcc, exec\n"
-        "s_cbranch_scc1 19f\n"
-        // ---- lg = log(|q|^2)  (log_normal)
-        "v_and_or_b32 v56, v44, s92, 0.5\n"                   // mantissa in [0.5, 1)
-        "v_lshrrev_b32_e32 v58, 23, v44\n"                    // biased exponent
-        "v_cmp_gt_f32_e32 vcc, 0x3f3504f3, v56\n"             // m < sqrt(1/2)
-        "v_add_u32_e32 v58, 0xffffff82, v58\n"                // e = biased - 126
-        "v_mul_f32_e32 v53, v43, v47\n"                       // dqs = dq * (4|q_last|^2)
-        "v_cndmask_b32_e32 v55, 0, v56, vcc\n"                // m or +0.0
-        "v_subbrev_co_u32_e32 v58, vcc, 0, v58, vcc\n"        // e -= 1 where m < sqrt(1/2)
-        "v_add_f32_e32 v56, v55, v56\n"                       // m + m  or  m
-        "v_add_f32_e32 v56, -1.0, v56\n"                      // reduced argument
-        "v_cvt_f32_i32_e32 v58, v58\n"                        // fe
-        "v_fmamk_f32 v57, v56, 0x3d9021bb, v59\n"             // Horner, 9 coefficients
-        "v_fmaak_f32 v57, v57, v56, 0x3def251a\n"
-        "v_fmaak_f32 v57, v57, v56, 0xbdfe5d4f\n"
-        "v_fmaak_f32 v57, v57, v56, 0x3e11e9bf\n"
-        "v_fmaak_f32 v57, v57, v56, 0xbe2aae50\n"
-        "v_fmaak_f32 v57, v57, v56, 0x3e4cceac\n"
-        "v_fmaak_f32 v57, v57, v56, 0xbe7ffffc\n"
-        "v_fmaak_f32 v57, v57, v56, 0x3eaaaaaa\n"
-        "v_pk_mul_f32 v[54:55], v[56:57], v[56:57] op_sel_hi:[0,1]\n"  // [z = m*m, p*m]
-        "v_mul_f32_e32 v55, v55, v54\n"                       // y = (p*m)*z
-        "v_fmac_f32_e32 v55, 0xb95e8083, v58\n"               // y = fma(fe, -2.12194440e-4, y)
-        "v_fmac_f32_e32 v55, -0.5, v54\n"                     // y = fma(-0.5, z, y)
-        "v_add_f32_e32 v55, v56, v55\n"                       // r = m + y
-        "v_fmac_f32_e32 v55, 0x3f318000, v58\n"               // lg = fma(fe, 0.693359375, r)
-        // ---- quot = |q|^2 / dqs, correctly rounded
-        "v_div_scale_f32 v60, s[82:83], v53, v53, v44\n"
-        "v_div_scale_f32 v61, vcc, v44, v53, v44\n"
-        "v_rcp_f32_e32 v62, v60\n"
-        "v_mul_f32_e32 v54, 0x3e800000, v55\n"                // 0.25 * lg
-        "v_fma_f32 v63, -v60, v62, 1.0\n"
-        "v_fmac_f32_e32 v62, v63, v62\n"
-        "v_mul_f32_e32 v63, v61, v62\n"
-        "v_fma_f32 v55, -v60, v63, v61\n"
-        "v_fmac_f32_e32 v63, v55, v62\n"
-        "v_fma_f32 v60, -v60, v63, v61\n"
-        "v_div_fmas_f32 v60, v60, v62, v63\n"
-        "v_div_fixup_f32 v60, v60, v53, v44\n"
-        // ---- root = sqrt(quot), correctly rounded
-        "v_mul_f32_e32 v61, 0x4f800000, v60\n"
-        "v_cmp_gt_f32_e32 vcc, 0x0f800000, v60\n"             // below 2^-96: work on quot * 2^32
-        "s_nop 1\n"
-        "v_cndmask_b32_e32 v60, v60, v61, vcc\n"
-        "v_sqrt_f32_e32 v61, v60\n"
-        "s_nop 0\n"
-        "v_add_u32_e32 v62, -1, v61\n"                        // candidates one ulp either side
-        "v_add_u32_e32 v63, 1, v61\n"
-        "v_fma_f32 v52, -v62, v61, v60\n"
-        "v_fma_f32 v56, -v63, v61, v60\n"
-        "v_cmp_ge_f32_e64 s[80:81], 0, v52\n"
-        "v_cmp_lt_f32_e64 s[82:83], 0, v56\n"
-        "s_nop 0\n"
-        "v_cndmask_b32_e64 v62, v61, v62, s[80:81]\n"
-        "v_cndmask_b32_e64 v61, v62, v63, s[82:83]\n"
-        "v_mul_f32_e32 v62, 0x37800000, v61\n"
-        "v_cndmask_b32_e32 v61, v61, v62, vcc\n"              // undo the 2^32 scaling
-        "v_cmp_class_f32_e64 vcc, v60, s94\n"               // sqrt(+-0) = +-0, sqrt(inf) = inf
-        "s_nop 1\n"
-        "v_cndmask_b32_e32 v60, v61, v60, vcc\n"
-        "v_mul_f32_e32 v54, v54, v60\n"                       // d = (0.25 lg) * root
-        // ---- lanes outside the bounding sphere: d = length(p) - 2 (julia.wgsl:8-9)
-        "40:\n"
-        "s_or_b64 exec, exec, s[78:79]\n"                     // all live lanes again
-        "s_cmp_lg_u64 s[78:79], 0\n"
-        "s_cbranch_scc1 45f\n"                                // out of line; comes back to 41
-        "41:\n"
-        // ---- hit test, advance
-        "v_cmp_gt_f32_e32 vcc, %[eps], v54\n"                 // d < epsilon
-        "s_or_b64 %[hit], %[hit], vcc\n"
-        "s_andn2_b64 exec, exec, vcc\n"                       // hit lanes freeze at their hit point
-        "v_add_f32_e32 v34, v34, v54\n"                       // t += d
-        "v_fma_f32 v32, v34, v35, %[ox]\n"                    // p = origin + t * dir
-        "v_pk_fma_f32 v[30:31], v[34:35], v[36:37], %[oyz] op_sel_hi:[0,1,1]\n"
-        "v_cmpx_gt_f32 vcc, %[maxd], v34\n"                   // t < max_distance; the others stop as misses
-        "s_add_u32 %[trips], %[trips], 1\n"
-        "s_cbranch_execz 18f\n"
-        "s_cmp_lt_i32 %[trips], %[maxit]\n"
-        "s_cbranch_scc1 10b\n"
-        "18:\n"                                               // nobody left, or out of iterations
-        "s_mov_b64 %[live], 0\n"
-        "s_branch 20f\n"
-        // ---- remainder trips (sdf_iters % 6), out of the hot line
-        "30:\n"
-        "s_mov_b32 s97, %[rem]\n"
-        "31:\n"
-        KIFS_FAST_TRIP
-        "s_sub_u32 s97, s97, 1\n"
-        "s_cmp_lg_u32 s97, 0\n"
-        "s_cbranch_scc1 31b\n"
-        "s_branch 12b\n"
-        // ---- sqrt(n2) - 2 for the outside lanes (n2 = v52 is still intact: the orbit lanes
-        //      only overwrite it inside their own sqrt, under their own exec)
-        "45:\n"
-        "s_add_u32 %[nout], %[nout], 1\n"                    // diagnostics: steps with outside lanes
-        "s_mov_b64 s[76:77], exec\n"
-        "s_mov_b64 exec, s[78:79]\n"
-        "v_mul_f32_e32 v61, 0x4f800000, v52\n"
-        "v_cmp_gt_f32_e32 vcc, 0x0f800000, v52\n"
-        "s_nop 1\n"
-        "v_cndmask_b32_e32 v60, v52, v61, vcc\n"
-        "v_sqrt_f32_e32 v61, v60\n"
-        "s_nop 0\n"
-        "v_add_u32_e32 v62, -1, v61\n"
-        "v_add_u32_e32 v63, 1, v61\n"
-        "v_fma_f32 v55, -v62, v61, v60\n"
-        "v_fma_f32 v56, -v63, v61, v60\n"
-        "v_cmp_ge_f32_e64 s[80:81], 0, v55\n"
-        "v_cmp_lt_f32_e64 s[82:83], 0, v56\n"
-        "s_nop 0\n"
-        "v_cndmask_b32_e64 v62, v61, v62, s[80:81]\n"
-        "v_cndmask_b32_e64 v61, v62, v63, s[82:83]\n"
-        "v_mul_f32_e32 v62, 0x37800000, v61\n"
-        "v_cndmask_b32_e32 v61, v61, v62, vcc\n"
-        "v_cmp_class_f32_e64 vcc, v60, s94\n"
-        "s_nop 1\n"
-        "v_cndmask_b32_e32 v60, v61, v60, vcc\n"
-        "v_add_f32_e32 v54, -2.0, v60\n"                      // d = norm - 2
-        // early ray termination: outside the sphere with margin and heading away from it, the
-        // ray cannot come back inside, so it can never hit: retire the lane as a miss now
-        "v_mul_f32_e32 v55, v32, v35\n"                       // dot(p, dir)
-        "v_fma_f32 v55, v30, v36, v55\n"
-        "v_fma_f32 v55, v31, v37, v55\n"
-        "v_cmp_lt_f32_e32 vcc, %[cull], v52\n"                // n2 > 1.1 R^2 (never when cull = 0 -> see below)
-        "v_cmp_lt_f32_e64 s[80:81], 0, v55\n"                 // moving outwards
-        "s_and_b64 vcc, vcc, s[80:81]\n"
-        "s_and_b64 vcc, vcc, s[74:75]\n"                      // culling enabled?
-        "s_andn2_b64 s[76:77], s[76:77], vcc\n"               // drop them from the live lanes
-        "s_mov_b64 exec, s[76:77]\n"
-        "s_branch 41b\n"
-        "19:\n"                                               // hand the current step to the general loop
-        "s_or_b64 %[live], exec, s[78:79]\n"
-        "20:\n"
-        "s_mov_b64 exec, s[84:85]\n"
-        : "+{v[30:31]}"(pyz), "+{v[32:33]}"(px1), "+{v[34:35]}"(tdx), [trips] "+s"(trips),
-          [hit] "+s"(hit_mask), [live] "=&s"(live_out), [nout] "+s"(outside_steps)
-        : "{v[36:37]}"(dyz), "{v[38:39]}"(w0), "{v59}"(c1), [oyz] "s"(oyz), [ox] "s"(P.origin.x),
-          [eps] "s"(P.epsilon), [maxd] "s"(P.max_distance), [bound] "s"(P.bound_n2), [cyz] "s"(cyz),
-          [cw0] "s"(cw0), [c0x] "s"(c0x), [maxit] "s"(P.max_iterations), [blocks] "s"(P.orbit_blocks),
-          [rem] "s"(P.orbit_rem), [lanes] "s"(lanes), [cull] "s"(P.cull_n2), [cullv] "v"(P.cull_n2)
-        : "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
-          "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62", "v63", "s84",
-          "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s96", "s97", "s74", "s75", "s76", "s77", "s78",
-          "s79", "s80", "s81", "s82", "s83");
+    if constexpr (SHORT_DIVSQRT) {
+#define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_ORDINARY
+#define KIFS_JULIA_DIVSQRT_OUT_OF_LINE "46:\n" KIFS_DIVSQRT_FULL "s_branch 47b\n"
+#include "kifs_julia_march_asm.hpp"
+#undef KIFS_JULIA_DIVSQRT
+#undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
+    } else {
+#define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_FULL
+#define KIFS_JULIA_DIVSQRT_OUT_OF_LINE
+#include "kifs_julia_march_asm.hpp"
+#undef KIFS_JULIA_DIVSQRT
+#undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
+    }
     const unsigned lane = __lane_id();
     p = V3{px1.x, pyz.x, pyz.y};
     t = tdx.x;
@@ -747,6 +644,8 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 // run through julia_interior), every marching lane outside (background: a sqrt and a
 // subtract), or mixed.  That keeps taken branches -- the expensive thing for a lone wave --
 // to the loop's back edge.
+// SHORT_DIVSQRT: the launcher's choice for frames with few SDF iterations (KIFS_DIVSQRT_ORDINARY).
+template <bool SHORT_DIVSQRT>
 KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps) {
     float t = 0.0f;
     V3 p = P.origin;
@@ -780,7 +679,7 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
             const int before = trips;
             unsigned long long t0 = 0;
             if (__builtin_expect(stamp, 0)) t0 = __builtin_amdgcn_s_memtime();
-            julia_fast_march(P, dir, t, p, hit, marching, trips, general_steps);
+            julia_fast_march<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, general_steps);
             if (__builtin_expect(stamp, 0)) fast_ticks += __builtin_amdgcn_s_memtime() - t0;
             ++fast_entries;
             fast_steps += trips - before;
@@ -921,7 +820,8 @@ KIFS_DEV V3 raymarch_with(const FrameParams& P, V3 dir, bool valid, int& steps, 
 
 template <int GROUP, int PRIM>
 KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
-    if constexpr (GROUP == GROUP_JULIA) return raymarch_julia(P, dir, valid, steps);
+    // for the Julia pipeline the PRIM slot carries the long-ray loop's variant (launch_render)
+    if constexpr (GROUP == GROUP_JULIA) return raymarch_julia<PRIM == 1>(P, dir, valid, steps);
     return raymarch_with(
         P, dir, valid, steps,
         [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); },

@@ -18,6 +18,8 @@ from enum import IntEnum
 import numpy as np
 
 from . import _lib
+
+MAX_BATCH = 8  # KIFS_MAX_BATCH of include/kifs_hip.h
 from ._lib import (CameraDataC, CameraUniform, ExtensionsC, GuiDataC, KifsError, OptionsUniform,
                    ScreenUniform, check, lib)
 
@@ -285,6 +287,32 @@ class GraphicState:
                                  "(the null stream handle selects the context's stream)")
         check(lib.kifs_render_async(self._ctx, stream, _device_pointer(out), pitch, y0, y1,
                                     encode), "render_async")
+
+    def render_batch_async(self, outs, cameras, stream=None, y0: int = 0, y1: int = None,
+                           encode: int = ENCODE_SRGB, pitch_bytes: int = None):
+        """One launch for len(outs) <= MAX_BATCH frames: frame i uses cameras[i] (CameraData or a
+        CameraUniform image) and goes to the device tensor outs[i]; screen, options, iteration
+        counts and extensions are the context's.  Enqueued on `stream` like render_async."""
+        if len(outs) != len(cameras) or not (1 <= len(outs) <= MAX_BATCH):
+            raise ValueError(f"render_batch_async: 1..{MAX_BATCH} frames, one camera each")
+        w, h = self.screen_data.width, self.screen_data.height
+        y1 = h if y1 is None else y1
+        pitch = pitch_bytes if pitch_bytes is not None else w * 4
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+            if not stream:
+                raise ValueError("render_batch_async: pass a non-default torch.cuda.Stream")
+        n = len(outs)
+        cams = (CameraUniform * n)(*[c.into_buffer_data() if hasattr(c, "into_buffer_data") else c
+                                     for c in cameras])
+        ptrs = (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
+        check(lib.kifs_render_batch_async(self._ctx, stream, n, cams, ptrs, pitch, y0, y1, encode),
+              "render_batch_async")
+
+    def set_frames_in_flight(self, n: int):
+        """Scheduling hint: the caller keeps n frames in flight on this device (one context and
+        stream each).  n > 1 trades the lone-frame residency cap for throughput."""
+        check(lib.kifs_set_frames_in_flight(self._ctx, int(n)), "set_frames_in_flight")
 
     def set_profiling(self, every: int = 1):
         """every = 0: off; 1: time every launch; n: every n-th launch."""

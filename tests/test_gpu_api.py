@@ -188,8 +188,8 @@ def test_single_process_multi_device_render(kifs, oracle):
 
 
 def test_tile_order_feedback_never_changes_pixels(gs, kifs, oracle):
-    """The tile order is re-derived every launch from the previous launches' per-tile costs by
-    a sort running on a side stream (Julia frames of >= 2048 tiles).  Order may only affect
+    """The tile order is re-derived every fourth launch from an earlier launch's per-tile costs
+    by a sort running on a side stream (Julia frames of >= 2048 tiles).  Order may only affect
     speed: 30 launches alternating between the full frame, a band, two caller streams and the
     context stream, with the camera moving, must all equal the oracle, and the order table
     must stay a permutation of the frame's tiles."""
@@ -231,6 +231,99 @@ def test_tile_order_feedback_never_changes_pixels(gs, kifs, oracle):
     # around the frame centre (x in {29, 30}, y in {66, 67, 68})
     first = {(int(o) & 0xffff, int(o) >> 16) for o in order[:4]}
     assert not first <= {(x, y) for x in (29, 30) for y in (66, 67, 68)}
+
+
+@pytest.mark.parametrize("scene", ["julia", "sierpinski", "bunny", "genjulia"])
+def test_batch_launch_equals_single_frames(scene, gs, kifs, oracle):
+    """kifs_render_batch_async: 1..8 frames per launch, one camera each, interleaved workgroups.
+    Every frame must equal the same frame rendered alone (and the oracle's), for full frames and
+    for a band that starts and ends inside a tile; the context's own camera is left alone."""
+    import torch
+    FG, PS = kifs.FractalGroup, kifs.PrimitiveShape
+    gui, iters, size = {
+        "julia": (kifs.GuiData(fractal_group=FG.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=96),
+                  (12, 10, 10), (330, 200)),
+        "sierpinski": (kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, max_iterations=96),
+                       (100, 10, 12), (300, 170)),
+        "bunny": (kifs.GuiData(primitive_shape=PS.Bunny, max_iterations=64), (100, 10, 10), (100, 60)),
+        "genjulia": (kifs.GuiData(fractal_group=FG.GeneralizedJuliaSet, power=3.0, max_iterations=48),
+                     (8, 4, 10), (120, 90)),
+    }[scene]
+    screen = kifs.ScreenData(*size)
+    W, H = size
+    own = kifs.CameraData(origin_distance=4.0, phi=0.3, theta=0.1)
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(*iters)
+    gs.set_camera(own)
+    cams = [kifs.CameraData(origin_distance=3.0 + 0.2 * k, phi=0.5 * k, theta=0.15 * k - 0.4) for k in range(8)]
+    stream = torch.cuda.Stream()
+    for n, (y0, y1) in [(1, (0, H)), (3, (0, H)), (8, (0, H)), (5, (5, H - 11))]:
+        outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(n)]
+        gs.render_batch_async(outs, cams[:n], stream=stream, y0=y0, y1=y1)
+        stream.synchronize()
+        for k in range(n):
+            want = oracle_frame(oracle, kifs, screen, cams[k], gui, iters, y0=y0, y1=y1)
+            assert (outs[k].cpu().numpy() == want).all(), (scene, n, k)
+    # the context's camera was not touched
+    assert (gs.render() == oracle_frame(oracle, kifs, screen, own, gui, iters)).all()
+    with pytest.raises(ValueError):
+        gs.render_batch_async([], [], stream=stream)
+
+
+def test_batch_launch_of_the_headline_workload(gs, kifs, oracle):
+    """Four 1080p Julia frames of an orbit in one launch (bench.py's default step) over several
+    launches, so that the tile-order feedback also runs on batched launches."""
+    import torch
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    W, H = w.screen.width, w.screen.height
+    gs.update_screen_data(w.screen)
+    gs.update_options(w.gui)
+    gs.set_iters(*w.iters)
+    stream = torch.cuda.Stream()
+    cams = [orbit_camera(w, 7 * k) for k in range(4)]
+    want = [oracle_frame(oracle, kifs, w.screen, c, w.gui, w.iters) for c in cams]
+    outs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+    for launch in range(7):
+        for o in outs:
+            o.zero_()
+        gs.render_batch_async(outs, cams, stream=stream)
+        stream.synchronize()
+        for k in range(4):
+            assert (outs[k].cpu().numpy() == want[k]).all(), (launch, k)
+
+
+def test_frames_in_flight_on_one_device(kifs, oracle):
+    """Three contexts with a stream each render an orbit concurrently (kifs_set_frames_in_flight:
+    no residency cap, kernels of different frames share the CUs); every frame equals the oracle's
+    and the hint rejects n < 1."""
+    import torch
+    from kifs_raymarching_amd._lib import lib
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    W, H = w.screen.width, w.screen.height
+    F = 3
+    ctxs = [kifs.GraphicState(0, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
+            for _ in range(F)]
+    try:
+        assert lib.kifs_set_frames_in_flight(ctxs[0]._ctx, 0) == 7  # BAD_ARG
+        streams = [torch.cuda.Stream() for _ in range(F)]
+        outs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(4 * F)]
+        for g in ctxs:
+            g.set_iters(*w.iters)
+            g.set_frames_in_flight(F)
+        poses = [orbit_camera(w, 10 * k) for k in range(4)]
+        for k in range(4 * F):  # pose k % 4 on context k % 3: every context sees every pose
+            ctxs[k % F].set_camera(poses[k % 4])
+            ctxs[k % F].render_async(outs[k], stream=streams[k % F], y0=0, y1=H)
+        torch.cuda.synchronize()
+        want = [oracle_frame(oracle, kifs, w.screen, cam, w.gui, w.iters) for cam in poses]
+        for k in range(4 * F):
+            assert (outs[k].cpu().numpy() == want[k % 4]).all(), k
+    finally:
+        for g in ctxs:
+            g.close()
 
 
 @pytest.mark.parametrize("scene", ["sierpinski", "torus", "julia", "bunny"])
