@@ -64,6 +64,7 @@ struct kifs_ctx {
     int sdf_iters = 100, normal_iters = 10, fold_iters = 10;  // julia.wgsl:2-3, kifs.wgsl:72
     KifsExtensions ext{};  // all zero: the reference's behaviour
     int frames_in_flight = 1;  // kifs_set_frames_in_flight
+    float h_srgb[256] = {};    // host copy of the sRGB threshold table (d_srgb)
     // per-launch profiling ring (kifs_set_profiling)
     bool profiling = false;
     int prof_every = 1;      // time every n-th launch
@@ -195,6 +196,9 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
         const float R = B + o.epsilon;
         const bool sane = B > 0.0f && R > 0.5f && R < 1.0e6f && o.epsilon >= 0.0f;
         P->cull_n2 = sane ? 1.1f * R * R : 0.0f;
+        // the wave-level quick exit uses a sphere 9 % larger again; like the culls, not in heatmap mode
+        P->quick_cull_n2 = (sane && !o.is_heatmap && o.max_iterations > 0) ? 1.2f * R * R : 0.0f;
+        P->inv_height = 1.0f / c->screen.height;
     }
     P->orbit_blocks = c->sdf_iters / 6;
     P->orbit_rem = c->sdf_iters % 6;
@@ -363,6 +367,23 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     P.y0 = y0;
     P.y1 = y1;
     P.encode = encode;
+    {   // the background pixel, encoded exactly as the kernels would (unorm8 / srgb8 of kifs_device_math.hpp)
+        uint32_t ch[3];
+        const float bg[3] = {P.background_color.x, P.background_color.y, P.background_color.z};
+        for (int i = 0; i < 3; ++i) {
+            const float x = bg[i];
+            if (encode == KIFS_ENCODE_SRGB) {
+                uint32_t k = 0;
+                for (uint32_t step = 128; step >= 1; step >>= 1) k += (x >= c->h_srgb[k + step]) ? step : 0u;
+                ch[i] = k;
+            } else {
+                float v = (x >= 0.0f) ? x : 0.0f;
+                v = (v > 1.0f) ? 1.0f : v;
+                ch[i] = uint32_t(int(v * 255.0f + 0.5f));
+            }
+        }
+        P.background_rgba = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
+    }
     P.pitch_words = uint32_t(pitch >> 2);
     P.out = reinterpret_cast<uint32_t*>(dev_out);
     if (y1 == y0) return KIFS_OK;
@@ -516,13 +537,13 @@ kifs_ctx* kifs_create(int device_ordinal, int* status) {
     kifs_ctx* c = new (std::nothrow) kifs_ctx();
     if (!c) return fail(KIFS_ERR_DEVICE_INIT);
     c->device = device_ordinal;
-    float table[256];
+    float* table = c->h_srgb;
     kifs::build_srgb_thresholds(table);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev_start) == hipSuccess &&
               hipEventCreate(&c->ev_stop) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&c->d_srgb), sizeof table) == hipSuccess &&
-              hipMemcpy(c->d_srgb, table, sizeof table, hipMemcpyHostToDevice) == hipSuccess;
+              hipMalloc(reinterpret_cast<void**>(&c->d_srgb), sizeof c->h_srgb) == hipSuccess &&
+              hipMemcpy(c->d_srgb, table, sizeof c->h_srgb, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {
         kifs_destroy(c);
         return fail(KIFS_ERR_DEVICE_INIT);

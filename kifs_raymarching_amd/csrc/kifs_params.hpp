@@ -51,6 +51,11 @@ struct FrameParams {
     // hand-written long-ray loop, [1] wave-steps taken on the general path, [2] entries into
     // the long-ray loop, [3] waves.  Enabled by kifs_debug_counters().
     unsigned long long* counters;
+    // Wave-level early exit (see wave_is_culled in kifs_kernels.hip): a cheaper, more conservative
+    // form of the bounding-sphere cull, evaluated before any ray is set up.  0 disables it.
+    float quick_cull_n2;                // 1.2 (B + epsilon)^2: well outside cull_n2
+    float inv_height;                   // ~1 / height (the quick test needs no exact uv)
+    uint32_t background_rgba;           // the encoded background pixel (same encoder, run on the host)
     // Host-side launch hint, not read by the kernels: how many workgroups may share a CU
     // (0 = no cap).  See residency_for() in kifs_api.cpp.
     int workgroups_per_cu;
