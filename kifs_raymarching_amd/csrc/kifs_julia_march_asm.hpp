@@ -96,8 +96,12 @@
         "v_cmpx_gt_f32 vcc, %[maxd], v34\n"                   // t < max_distance; the others stop as misses
         "s_add_u32 %[trips], %[trips], 1\n"
         "s_cbranch_execz 18f\n"
-        "s_cmp_lt_i32 %[trips], %[maxit]\n"
+        "s_cmp_lt_i32 %[trips], %[limit]\n"                  // limit = min(max_iterations, end of the round)
         "s_cbranch_scc1 10b\n"
+        "s_cmp_lt_i32 %[trips], %[maxit]\n"
+        "s_cbranch_scc0 18f\n"
+        "s_mov_b64 %[live], exec\n"                          // end of a round: these lanes march on next round
+        "s_branch 20f\n"
         "18:\n"                                               // nobody left, or out of iterations
         "s_mov_b64 %[live], 0\n"
         "s_branch 20f\n"
@@ -158,7 +162,7 @@
           [hit] "+s"(hit_mask), [live] "=&s"(live_out), [nout] "+s"(outside_steps)
         : "{v[36:37]}"(dyz), "{v[38:39]}"(w0), "{v59}"(c1), [oyz] "s"(oyz), [ox] "s"(P.origin.x),
           [eps] "s"(P.epsilon), [maxd] "s"(P.max_distance), [bound] "s"(P.bound_n2), [cyz] "s"(cyz),
-          [cw0] "s"(cw0), [c0x] "s"(c0x), [maxit] "s"(P.max_iterations), [blocks] "s"(P.orbit_blocks),
+          [cw0] "s"(cw0), [c0x] "s"(c0x), [maxit] "s"(P.max_iterations), [limit] "s"(limit), [blocks] "s"(P.orbit_blocks),
           [rem] "s"(P.orbit_rem), [lanes] "s"(lanes), [cull] "s"(P.cull_n2), [cullv] "v"(P.cull_n2)
         : "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
           "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62", "v63", "s84",

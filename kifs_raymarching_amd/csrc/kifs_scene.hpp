@@ -611,7 +611,7 @@ KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit, Sdf
 
 template <bool SHORT_DIVSQRT>
 KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit,
-                               bool& marching, int& trips, int& outside_steps) {
+                               bool& marching, int& trips, int& outside_steps, int limit) {
     F2 pyz{p.y, p.z}, px1{p.x, 1.0f}, tdx{t, dir.x};
     const F2 dyz{dir.y, dir.z}, w0{0.1f, 1.0f};
     const F2 oyz{P.origin.y, P.origin.z}, cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x};
@@ -644,46 +644,46 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 // run through julia_interior), every marching lane outside (background: a sqrt and a
 // subtract), or mixed.  That keeps taken branches -- the expensive thing for a lone wave --
 // to the loop's back edge.
+// A ray that can never come within the cull radius of the origin (see fill_params): decided at
+// ray set-up from the closest approach of the ray's line.
+KIFS_DEV bool ray_never_inside(const FrameParams& P, V3 dir) {
+    const float oo = dot(P.origin, P.origin);
+    const float b = -dot(P.origin, dir);
+    const float c2 = fmaf_(-b, b, oo);
+    return (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
+}
+
 // SHORT_DIVSQRT: the launcher's choice for frames with few SDF iterations (KIFS_DIVSQRT_ORDINARY).
-template <bool SHORT_DIVSQRT>
-KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps) {
-    float t = 0.0f;
-    V3 p = P.origin;
-    bool hit = false;
-    int trips = 0;     // == the loop counter i of entry.wgsl:11 for every marching lane
-    int i_final = 0;
-    bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
-    // Bounding-sphere cull.  Outside the sphere of radius R = 2 + epsilon the estimate is
-    // length(p) - 2 > epsilon (julia.wgsl:8-9), so a ray that never enters the sphere can never
-    // satisfy `d < epsilon`: its pixel is background whatever else the loop does (only the
-    // heatmap's step count would notice).  The test keeps a 10 % margin on R^2, orders of
-    // magnitude above the rounding of p = fma(t, dir, origin) for any t < max_distance.
-    if (P.is_heatmap == 0u && P.cull_n2 > 0.0f) {
-        const float oo = dot(P.origin, P.origin);
-        const float b = -dot(P.origin, dir);            // parameter of closest approach
-        const float c2 = fmaf_(-b, b, oo);              // squared distance at closest approach
-        const bool never_inside = (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
-        marching = marching && !never_inside;
-    }
-    const bool fast_ok = (P.is_heatmap == 0u) && (P.sdf_iters >= 1);  // wave-uniform
-    int fast_steps = 0, fast_entries = 0, general_steps = 0;        // diagnostics (SGPRs)
+struct JuliaDiag {  // diagnostics of one wave's march (SGPRs)
+    int fast_steps = 0, fast_entries = 0, general_steps = 0;
     unsigned long long fast_ticks = 0;
-    const bool stamp = P.counters != nullptr;
-    const unsigned long long wave_t0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+};
+
+// The march loop proper: steps the wave's marching lanes until none is left or `trips` reaches
+// `limit` (max_iterations for a whole ray, the end of the current round when the workgroup
+// re-queues its rays).  State in, state out; i_final is the heatmap's loop counter.
+template <bool SHORT_DIVSQRT>
+KIFS_DEV void julia_loop(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit, bool& marching,
+                         int& trips, int& i_final, int limit, JuliaDiag& diag, bool stamp) {
+    const bool fast_ok = (P.is_heatmap == 0u) && (P.sdf_iters >= 1);  // wave-uniform
     for (;;) {
         const unsigned long long live = __builtin_amdgcn_ballot_w64(marching);
-        if (live == 0ull) break;
+        if (live == 0ull || trips >= limit) break;
         if (__builtin_expect(fast_ok, 1)) {
             // The hand-written loop takes whole steps for inside and outside lanes alike; it only
             // comes back when it meets a |q|^2 that needs the general log (or it is finished).
             const int before = trips;
-            unsigned long long t0 = 0;
-            if (__builtin_expect(stamp, 0)) t0 = __builtin_amdgcn_s_memtime();
-            julia_fast_march<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, general_steps);
-            if (__builtin_expect(stamp, 0)) fast_ticks += __builtin_amdgcn_s_memtime() - t0;
-            ++fast_entries;
-            fast_steps += trips - before;
-            if (__builtin_amdgcn_ballot_w64(marching) == 0ull) break;
+            // (unconditional: two s_memtime per entry cost nothing, and the conditional form trips the
+            // compiler's SGPR handling around the asm block)
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            int outside_steps = 0;  // (a fresh SGPR for the asm block: struct members confuse the allocator)
+            julia_fast_march<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, outside_steps,
+                                            limit < P.max_iterations ? limit : P.max_iterations);
+            diag.general_steps += outside_steps;
+            diag.fast_ticks += __builtin_amdgcn_s_memtime() - t0;
+            ++diag.fast_entries;
+            diag.fast_steps += trips - before;
+            if (__builtin_amdgcn_ballot_w64(marching) == 0ull || trips >= limit) break;
         }
         const bool more = (trips + 1) < P.max_iterations;
         const float n2 = dot(p, p);
@@ -711,8 +711,41 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
                go ? fmaf_(tn, dir.z, P.origin.z) : p.z};
         marching = go && more && (tn < P.max_distance);
         ++trips;
-        ++general_steps;
+        ++diag.general_steps;
     }
+}
+
+// Colour of a Julia hit at p (entry.wgsl:14-19 with julia.wgsl:29-56), soft shadows if enabled.
+KIFS_DEV V3 julia_shade(const FrameParams& P, V3 p) {
+    V3 n = julia_normal(P, p);
+    float ndl = (n.x + n.y) + n.z;
+    float lit = clamp_(ndl, 0.0f, 1.0f);
+    if (__builtin_expect(P.soft_shadow != 0u, 0))
+        lit = lit * soft_shadow(P, p, n, true, [&](V3 q, unsigned long long) { return julia_sdf(P, q); });
+    float diffuse = fmaf_(0.9f, lit, 0.1f);
+    return V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
+}
+
+// A whole ray per lane, start to finish (heatmap mode, diagnostics, and the building block the
+// re-queuing kernel path is checked against).
+template <bool SHORT_DIVSQRT>
+KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps) {
+    float t = 0.0f;
+    V3 p = P.origin;
+    bool hit = false;
+    int trips = 0;     // == the loop counter i of entry.wgsl:11 for every marching lane
+    int i_final = 0;
+    bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
+    // Bounding-sphere cull.  Outside the sphere of radius R = 2 + epsilon the estimate is
+    // length(p) - 2 > epsilon (julia.wgsl:8-9), so a ray that never enters the sphere can never
+    // satisfy `d < epsilon`: its pixel is background whatever else the loop does (only the
+    // heatmap's step count would notice).  The test keeps a 10 % margin on R^2, orders of
+    // magnitude above the rounding of p = fma(t, dir, origin) for any t < max_distance.
+    if (P.is_heatmap == 0u && P.cull_n2 > 0.0f) marching = marching && !ray_never_inside(P, dir);
+    JuliaDiag diag;
+    const bool stamp = P.counters != nullptr;
+    const unsigned long long wave_t0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+    julia_loop<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, i_final, P.max_iterations, diag, stamp);
     __builtin_amdgcn_s_setprio(0);
     steps = trips;
     if (__builtin_expect(stamp, 0)) {
@@ -722,21 +755,13 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
         if (__lane_id() == 0) {
             unsigned long long* rec = P.counters + 8 + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
             rec[0] = wave_t1 - wave_t0;
-            rec[1] = fast_ticks;
-            rec[2] = (unsigned long long)fast_steps | ((unsigned long long)fast_entries << 32);
-            rec[3] = (unsigned long long)general_steps;
+            rec[1] = diag.fast_ticks;
+            rec[2] = (unsigned long long)diag.fast_steps | ((unsigned long long)diag.fast_entries << 32);
+            rec[3] = (unsigned long long)diag.general_steps;
         }
     }
     V3 colour = P.background_color;
-    if (hit) {
-        V3 n = julia_normal(P, p);
-        float ndl = (n.x + n.y) + n.z;
-        float lit = clamp_(ndl, 0.0f, 1.0f);
-        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow(P, p, n, true, [&](V3 q, unsigned long long) { return julia_sdf(P, q); });
-        float diffuse = fmaf_(0.9f, lit, 0.1f);
-        colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
-                    diffuse * P.fractal_color.z};
-    }
+    if (hit) colour = julia_shade(P, p);
     if (P.is_heatmap) {
         float f = float(i_final) / float(P.max_iterations);
         colour = V3{f * P.fractal_color.x, f * P.fractal_color.y, f * P.fractal_color.z};
@@ -744,37 +769,16 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
     return colour;
 }
 
-// ---- raymarch (entry.wgsl:6-29), wave64 form ------------------------------------------
-// Lanes march in lock step; a lane drops out on hit, on i == max_iterations or on
-// t >= max_distance.  The loop leaves as soon as __ballot says no lane is still
-// marching (wave-level early ray termination); normals are evaluated once, after
-// the loop, for the lanes that hit, so that divergent work is bunched together.
-// A ray that can never come within the cull radius of the origin (see fill_params): decided at
-// ray set-up from the closest approach of the ray's line.
-KIFS_DEV bool ray_never_inside(const FrameParams& P, V3 dir) {
-    const float oo = dot(P.origin, P.origin);
-    const float b = -dot(P.origin, dir);
-    const float c2 = fmaf_(-b, b, oo);
-    return (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
-}
-
 // `sdf(p, lanes)`: the scene's estimate (lanes = whose value is used); `normal(p)`: its normal.
-template <class Sdf, class Normal>
-KIFS_DEV V3 raymarch_with(const FrameParams& P, V3 dir, bool valid, int& steps, Sdf sdf, Normal normal) {
-    float t = 0.0f;
-    V3 p = P.origin;
-    bool hit = false;
-    // Every marching lane has made the same number of steps, so the loop counter `i` of
-    // entry.wgsl:11 is the wave-uniform trip count (an SGPR); a lane records it when it stops.
-    int trips = 0;
-    int i_final = 0;
-    bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
+// The march loop proper, as julia_loop: until no lane marches or `trips` reaches `limit`.
+template <class Sdf>
+KIFS_DEV void generic_loop(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit, bool& marching,
+                           int& trips, int& i_final, int limit, Sdf sdf) {
     // Bounding-sphere culls (see raymarch_julia and fill_params): every scene's estimate obeys
-    // d(p) >= |p| - B, so a ray that never comes within R = B + epsilon of the origin, or a lane
-    // outside R and moving away, can never satisfy `d < epsilon`.  Not in heatmap mode.
+    // d(p) >= |p| - B, so a lane outside R = B + epsilon and moving away can never satisfy
+    // `d < epsilon`.  Not in heatmap mode.
     const bool cull = (P.is_heatmap == 0u) && (P.cull_n2 > 0.0f);  // wave-uniform
-    if (cull) marching = marching && !ray_never_inside(P, dir);
-    while (__builtin_amdgcn_ballot_w64(marching) != 0ull) {
+    while (__builtin_amdgcn_ballot_w64(marching) != 0ull && trips < limit) {
         // a ray still marching after 32 steps is on the frame's critical path: issue it first
         if (trips == 32) __builtin_amdgcn_s_setprio(3);
         const bool more = (trips + 1) < P.max_iterations;  // scalar
@@ -799,18 +803,36 @@ KIFS_DEV V3 raymarch_with(const FrameParams& P, V3 dir, bool valid, int& steps, 
         marching = go && more && (tn < P.max_distance);
         ++trips;
     }
+}
+
+// Colour of a hit at p (entry.wgsl:14-19), soft shadows if enabled.
+template <class Sdf, class Normal>
+KIFS_DEV V3 generic_shade(const FrameParams& P, V3 p, Sdf sdf, Normal normal) {
+    V3 n = normal(p);
+    float ndl = (n.x + n.y) + n.z;  // dot(n, (1,1,1)): the light is not normalised (:17)
+    float lit = clamp_(ndl, 0.0f, 1.0f);
+    if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow(P, p, n, true, sdf);
+    float diffuse = fmaf_(0.9f, lit, 0.1f);
+    return V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
+}
+
+// A whole ray per lane, start to finish.
+template <class Sdf, class Normal>
+KIFS_DEV V3 raymarch_with(const FrameParams& P, V3 dir, bool valid, int& steps, Sdf sdf, Normal normal) {
+    float t = 0.0f;
+    V3 p = P.origin;
+    bool hit = false;
+    // Every marching lane has made the same number of steps, so the loop counter `i` of
+    // entry.wgsl:11 is the wave-uniform trip count (an SGPR); a lane records it when it stops.
+    int trips = 0;
+    int i_final = 0;
+    bool marching = valid && (0 < P.max_iterations) && (t < P.max_distance);
+    if ((P.is_heatmap == 0u) && (P.cull_n2 > 0.0f)) marching = marching && !ray_never_inside(P, dir);
+    generic_loop(P, dir, t, p, hit, marching, trips, i_final, P.max_iterations, sdf);
     __builtin_amdgcn_s_setprio(0);
     steps = trips;
     V3 colour = P.background_color;
-    if (hit) {
-        V3 n = normal(p);
-        float ndl = (n.x + n.y) + n.z;  // dot(n, (1,1,1)): the light is not normalised (:17)
-        float lit = clamp_(ndl, 0.0f, 1.0f);
-        if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow(P, p, n, true, sdf);
-        float diffuse = fmaf_(0.9f, lit, 0.1f);
-        colour = V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y,
-                    diffuse * P.fractal_color.z};
-    }
+    if (hit) colour = generic_shade(P, p, sdf, normal);
     if (P.is_heatmap) {
         float f = float(i_final) / float(P.max_iterations);
         colour = V3{f * P.fractal_color.x, f * P.fractal_color.y, f * P.fractal_color.z};
