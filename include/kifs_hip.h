@@ -248,6 +248,9 @@ int kifs_eval_math(kifs_ctx* ctx, int fn, const float* in, float param, float* o
  * device buffer sized for the current screen; each call zeroes the buffer (out[8] receives
  * the 8 reserved header words).  enable == 0 frees it.  Not for timed runs. */
 int kifs_debug_counters(kifs_ctx* ctx, int enable, unsigned long long out[8]);
+/* Round length (march steps) of the ray re-queuing used by the context's latest launch; 0 = that
+ * launch marched one wave per 8x8 block.  For tests. */
+int kifs_debug_last_round_steps(kifs_ctx* ctx);
 /* Tuning hooks: read / replace the order in which workgroups take the tiles of the full
  * frame (a permutation of (tile_x | tile_y << 16)); the order only affects speed. */
 int kifs_debug_get_tile_order(kifs_ctx* ctx, uint32_t* order, size_t max_count, size_t* count);

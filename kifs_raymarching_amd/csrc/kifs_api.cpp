@@ -64,6 +64,7 @@ struct kifs_ctx {
     int sdf_iters = 100, normal_iters = 10, fold_iters = 10;  // julia.wgsl:2-3, kifs.wgsl:72
     KifsExtensions ext{};  // all zero: the reference's behaviour
     int frames_in_flight = 1;  // kifs_set_frames_in_flight
+    int last_round_steps = 0;  // kifs_debug_last_round_steps
     float h_srgb[256] = {};    // host copy of the sRGB threshold table (d_srgb)
     // per-launch profiling ring (kifs_set_profiling)
     bool profiling = false;
@@ -199,6 +200,19 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
         // the wave-level quick exit uses a sphere 9 % larger again; like the culls, not in heatmap mode
         P->quick_cull_n2 = (sane && !o.is_heatmap && o.max_iterations > 0) ? 1.2f * R * R : 0.0f;
         P->inv_height = 1.0f / c->screen.height;
+    }
+    {   // Ray re-queuing (render_kernel): rounds of this many march steps -- 32 for the Julia
+        // pipeline, 16 for the others (measured; KIFS_ROUND_STEPS overrides, 0 switches it off).
+        // Not for heatmap frames (their per-ray step count is kept by the one-wave-per-block
+        // march), not with a non-positive epsilon (the queue rebuilds p from t and relies on
+        // t > 0 after a step), not for marches too short to repay the rounds' barriers.
+        static const int forced = [] {
+            const char* e = std::getenv("KIFS_ROUND_STEPS");
+            return e ? int(std::strtol(e, nullptr, 10)) : -1;
+        }();
+        int rounds = forced >= 0 ? forced : (o.fractal_group_id == uint32_t(kifs::GROUP_JULIA) ? 32 : 16);
+        if (o.is_heatmap || !(o.epsilon > 0.0f) || o.max_iterations < 2 * rounds) rounds = 0;
+        P->round_steps = rounds;
     }
     P->orbit_blocks = c->sdf_iters / 6;
     P->orbit_rem = c->sdf_iters % 6;
@@ -453,12 +467,18 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     P.tile_order = tt->d_order;
     P.tile_count = tt->count;
     P.tile_cost = record_costs ? tt->d_cost[0] : nullptr;
+    if (P.counters) P.round_steps = 0;  // the per-wave diagnostics belong to the one-wave-per-block march
     // the residency cap serves a lone frame's latency; concurrent frames want every slot
     P.workgroups_per_cu = (c->frames_in_flight > 1 || count > 1)
                               ? 0 : residency_for(P, c->options.fractal_group_id, h, tt->count);
+    // a residency-capped launch is a lone frame bound by its longest rays: re-queuing helps
+    // throughput, not that (1080p Julia: 0.143 ms without, 0.146 ms with)
+    if (P.workgroups_per_cu >= 1) P.round_steps = 0;
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
     const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
     if (timed && !hip_ok(hipEventRecord(c->prof_a[pslot], stream), "record(profile start)")) return KIFS_ERR_RUNTIME;
+    c->last_round_steps = (c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS) &&
+                           c->options.primitive_id == uint32_t(kifs::PRIM_BUNNY)) ? 0 : P.round_steps;
     hipError_t e = kifs::launch_render(B, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
     if (!hip_ok(e, "render_kernel launch")) return KIFS_ERR_RUNTIME;
@@ -686,6 +706,8 @@ int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int enc
 }
 
 double kifs_last_kernel_ms(kifs_ctx* c) { return c ? c->last_ms : -1.0; }
+
+int kifs_debug_last_round_steps(kifs_ctx* c) { return c ? c->last_round_steps : -1; }
 
 int kifs_set_frames_in_flight(kifs_ctx* c, int n) {
     if (!c || n < 1) return KIFS_ERR_BAD_ARG;

@@ -92,50 +92,185 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
     const int y = P.y0 + tile_y + ly;
     const bool valid = (x < P.width) && (y < P.y1);
 
-    V3 colour{0.0f, 0.0f, 0.0f};
-    int steps = 0;  // wave-uniform: march steps this wave needed
     const bool feedback = P.tile_cost != nullptr;  // wave-uniform
     const unsigned long long wave_start = feedback ? __builtin_amdgcn_s_memtime() : 0ull;
     const bool culled = wave_is_culled(P, x, y, valid);  // wave-uniform
-    if (!culled && __ballot(valid) != 0ull) {
-        V3 dir = ray_direction(P, x, y);
-        colour = raymarch<GROUP, PRIM>(P, dir, valid, steps);
-    }
-    // cost of this wave for the next frame's tile order: its run time in units of 1024 cycles,
-    // minus a floor that maps culled / instant waves to 0 (march steps alone are too coarse:
-    // hundreds of tiles tie at max_iterations)
-    if (feedback) {
-        const unsigned long long wave_cycles = __builtin_amdgcn_s_memtime() - wave_start;
-        if (lane == 0)
-            s_steps[wave] = int(min(wave_cycles > 4096ull ? (wave_cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
-    }
-    (void)steps;
+    const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
+    uint32_t* const cost_slot = feedback ? &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)] : nullptr;
 
-    __syncthreads();  // s_srgb and s_steps visible
-    // cost feedback for the next frame's tile order: the tile's slowest wave
-    if (tid == 0 && feedback) {
-        const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
-        const int m = max(max(s_steps[0], s_steps[1]), max(s_steps[2], s_steps[3]));
-        uint32_t* cost = &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)];
-        if (batch > 1) atomicMax(cost, uint32_t(m));  // the batch's views share the table (the sort clears it)
-        else *cost = uint32_t(m);
-    }
-    uint32_t rgba = P.background_rgba;
-    if (!culled) {
-        uint32_t r, g, b;
-        if (srgb) {
-            r = srgb8(colour.x, s_srgb);
-            g = srgb8(colour.y, s_srgb);
-            b = srgb8(colour.z, s_srgb);
-        } else {
-            r = unorm8(colour.x);
-            g = unorm8(colour.y);
-            b = unorm8(colour.z);
+    if (P.round_steps > 0) {
+        // ---- ray re-queuing --------------------------------------------------------------
+        // Rays of one 8x8 block leave the march at very different steps (measured: 54-66 % of the
+        // lanes of a VALU instruction are live).  So the workgroup keeps its live rays in an LDS
+        // queue and marches in rounds of `round_steps` steps: a round takes the queue's rays 64 at
+        // a time -- full waves -- and every ray ends the round in one of three places: the queue
+        // of the next round, the hit list, or nowhere (a miss keeps the pre-filled background).
+        // Hits are shaded at the end, again 64 at a time.  A ray's own arithmetic is unchanged
+        // (t, and p = fma(t, dir, origin) rebuilt from it exactly as the march itself does), all
+        // rays of the workgroup make their k-th step in the same round (the step counter stays
+        // uniform), and pixels do not interact: same pixels as the one-wave-per-block march.
+        __shared__ uint32_t q_pix[2][BLOCK];
+        __shared__ float q_t[2][BLOCK], q_dx[2][BLOCK], q_dy[2][BLOCK], q_dz[2][BLOCK];
+        __shared__ uint32_t h_pix[BLOCK];
+        __shared__ float h_t[BLOCK], h_dx[BLOCK], h_dy[BLOCK], h_dz[BLOCK];
+        __shared__ uint32_t q_count[2], h_count;
+        if (tid == 0) {
+            q_count[0] = 0;
+            q_count[1] = 0;
+            h_count = 0;
         }
-        rgba = r | (g << 8) | (b << 16) | 0xff000000u;  // alpha = 1.0 -> 255
+        s_tile[ly][lx] = P.background_rgba;
+        __syncthreads();
+        {   // round 0's queue: the rays that survive the culls
+            bool alive = false;
+            V3 dir{0.0f, 0.0f, 0.0f};
+            if (!culled && __ballot(valid) != 0ull) {
+                dir = ray_direction(P, x, y);
+                alive = valid && (0 < P.max_iterations) && (0.0f < P.max_distance);
+                if (P.cull_n2 > 0.0f) alive = alive && !ray_never_inside(P, dir);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+            if (m != 0ull) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&q_count[0], uint32_t(__builtin_popcountll(m)));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (alive) {
+                    const uint32_t i = base + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+                    q_pix[0][i] = uint32_t(lx) | (uint32_t(ly) << 8);
+                    q_t[0][i] = 0.0f;
+                    q_dx[0][i] = dir.x;
+                    q_dy[0][i] = dir.y;
+                    q_dz[0][i] = dir.z;
+                }
+            }
+        }
+        __syncthreads();
+        int trips = 0;
+        for (uint32_t cur = 0;; cur ^= 1u) {
+            const uint32_t n = q_count[cur];  // uniform
+            if (n == 0u) break;
+            const uint32_t idx = uint32_t(tid);
+            const bool have = idx < n;
+            uint32_t pix = 0;
+            float t = 0.0f;
+            V3 dir{0.0f, 0.0f, 1.0f};
+            if (have) {
+                pix = q_pix[cur][idx];
+                t = q_t[cur][idx];
+                dir = V3{q_dx[cur][idx], q_dy[cur][idx], q_dz[cur][idx]};
+            }
+            __syncthreads();  // everyone has read queue `cur` and its count
+            if (tid == 0) q_count[cur] = 0;  // it is the queue of the round after next
+            const int limit = min(trips + P.round_steps, P.max_iterations);
+            if (uint32_t(wave) * 64u < n) {  // wave-uniform: this wave has rays
+                // a ray that has advanced has t > 0 (epsilon > 0 on this path), and then its
+                // position is what the march last computed: fma(t, dir, origin)
+                V3 p = (trips == 0) ? P.origin
+                                    : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                                         fmaf_(t, dir.z, P.origin.z)};
+                bool hit = false, marching = have;
+                int wave_trips = trips;
+                march_round<GROUP, PRIM>(P, dir, t, p, hit, marching, wave_trips, limit);
+                __builtin_amdgcn_s_setprio(0);
+                const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
+                const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);
+                uint32_t bh = 0, bq = 0;
+                if (lane == 0) {
+                    if (mh) bh = atomicAdd(&h_count, uint32_t(__builtin_popcountll(mh)));
+                    if (mq) bq = atomicAdd(&q_count[cur ^ 1u], uint32_t(__builtin_popcountll(mq)));
+                }
+                bh = __builtin_amdgcn_readfirstlane(bh);
+                bq = __builtin_amdgcn_readfirstlane(bq);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (hit) {
+                    const uint32_t i = bh + uint32_t(__builtin_popcountll(mh & below));
+                    h_pix[i] = pix;
+                    h_t[i] = t;
+                    h_dx[i] = dir.x;
+                    h_dy[i] = dir.y;
+                    h_dz[i] = dir.z;
+                } else if (marching) {
+                    const uint32_t i = bq + uint32_t(__builtin_popcountll(mq & below));
+                    q_pix[cur ^ 1u][i] = pix;
+                    q_t[cur ^ 1u][i] = t;
+                    q_dx[cur ^ 1u][i] = dir.x;
+                    q_dy[cur ^ 1u][i] = dir.y;
+                    q_dz[cur ^ 1u][i] = dir.z;
+                }
+            }
+            trips = limit;
+            __syncthreads();  // the next queue and the hit list are complete
+        }
+        {   // shade the hits, 64 to a wave
+            const uint32_t m = h_count;
+            if (uint32_t(tid) < m) {
+                const uint32_t pix = h_pix[tid];
+                const float t = h_t[tid];
+                const V3 dir{h_dx[tid], h_dy[tid], h_dz[tid]};
+                const V3 p = (t == 0.0f) ? P.origin
+                                         : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                                              fmaf_(t, dir.z, P.origin.z)};
+                const V3 colour = shade_hit<GROUP, PRIM>(P, p);
+                uint32_t r, g, b;
+                if (srgb) {
+                    r = srgb8(colour.x, s_srgb);
+                    g = srgb8(colour.y, s_srgb);
+                    b = srgb8(colour.z, s_srgb);
+                } else {
+                    r = unorm8(colour.x);
+                    g = unorm8(colour.y);
+                    b = unorm8(colour.z);
+                }
+                s_tile[pix >> 8][pix & 0xffu] = r | (g << 8) | (b << 16) | 0xff000000u;
+            }
+        }
+        if (tid == 0 && feedback) {  // cost of the tile: the workgroup's run time
+            const unsigned long long cycles = __builtin_amdgcn_s_memtime() - wave_start;
+            const uint32_t m = uint32_t(min(cycles > 4096ull ? (cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
+            if (batch > 1) atomicMax(cost_slot, m);
+            else *cost_slot = m;
+        }
+        __syncthreads();
+    } else {
+        // ---- one wave per 8x8 block, start to finish (heatmap frames, diagnostics) -----------
+        V3 colour{0.0f, 0.0f, 0.0f};
+        int steps = 0;  // wave-uniform: march steps this wave needed
+        if (!culled && __ballot(valid) != 0ull) {
+            V3 dir = ray_direction(P, x, y);
+            colour = raymarch<GROUP, PRIM>(P, dir, valid, steps);
+        }
+        // cost of this wave for the next frame's tile order: its run time in units of 1024 cycles,
+        // minus a floor that maps culled / instant waves to 0 (march steps alone are too coarse:
+        // hundreds of tiles tie at max_iterations)
+        if (feedback) {
+            const unsigned long long wave_cycles = __builtin_amdgcn_s_memtime() - wave_start;
+            if (lane == 0)
+                s_steps[wave] = int(min(wave_cycles > 4096ull ? (wave_cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
+        }
+        (void)steps;
+        __syncthreads();  // s_srgb and s_steps visible
+        if (tid == 0 && feedback) {  // the tile's slowest wave
+            const int m = max(max(s_steps[0], s_steps[1]), max(s_steps[2], s_steps[3]));
+            if (batch > 1) atomicMax(cost_slot, uint32_t(m));  // the batch's views share the table (the sort clears it)
+            else *cost_slot = uint32_t(m);
+        }
+        uint32_t rgba = P.background_rgba;
+        if (!culled) {
+            uint32_t r, g, b;
+            if (srgb) {
+                r = srgb8(colour.x, s_srgb);
+                g = srgb8(colour.y, s_srgb);
+                b = srgb8(colour.z, s_srgb);
+            } else {
+                r = unorm8(colour.x);
+                g = unorm8(colour.y);
+                b = unorm8(colour.z);
+            }
+            rgba = r | (g << 8) | (b << 16) | 0xff000000u;  // alpha = 1.0 -> 255
+        }
+        s_tile[ly][lx] = rgba;
+        __syncthreads();
     }
-    s_tile[ly][lx] = rgba;
-    __syncthreads();
 
     // store mapping: thread -> (tid & 31, tid >> 5): linear rows of 128 bytes
     const int sx = tid & (TILE_W - 1), sy = tid >> 5;
@@ -215,10 +350,10 @@ static unsigned residency_pad_bytes(int workgroups_per_cu) {
         return e ? std::strtol(e, nullptr, 10) : -1L;
     }();
     if (forced >= 0) return unsigned(forced);
-    switch (workgroups_per_cu) {  // static LDS is 2 KiB; a CU has 160 KiB
+    switch (workgroups_per_cu) {  // static LDS is 18 KiB (ray queues); a CU has 160 KiB
     case 1: return 100 * 1024;
-    case 2: return 72 * 1024;
-    case 3: return 50 * 1024;
+    case 2: return 55 * 1024;
+    case 3: return 34 * 1024;
     default: return 0;
     }
 }

@@ -56,6 +56,9 @@ struct FrameParams {
     float quick_cull_n2;                // 1.2 (B + epsilon)^2: well outside cull_n2
     float inv_height;                   // ~1 / height (the quick test needs no exact uv)
     uint32_t background_rgba;           // the encoded background pixel (same encoder, run on the host)
+    // Ray re-queuing (render_kernel): march steps per round between two re-packings of the
+    // workgroup's surviving rays into full waves; 0 = every wave marches its own 64 pixels to the end.
+    int round_steps;
     // Host-side launch hint, not read by the kernels: how many workgroups may share a CU
     // (0 = no cap).  See residency_for() in kifs_api.cpp.
     int workgroups_per_cu;

@@ -850,6 +850,31 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
         [&](V3 q) { return scene_normal<GROUP, PRIM>(P, q); });
 }
 
+// One round of the workgroup's ray queue for pipeline <GROUP, PRIM>: step the wave's lanes until
+// `trips` reaches `limit`; and the colour of a hit.  (For the Julia pipeline the PRIM slot is the
+// variant of the long-ray loop, see raymarch.)
+template <int GROUP, int PRIM>
+KIFS_DEV void march_round(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit, bool& marching,
+                          int& trips, int limit) {
+    int i_final = 0;  // heatmap frames do not take this path
+    if constexpr (GROUP == GROUP_JULIA) {
+        JuliaDiag diag;
+        julia_loop<PRIM == 1>(P, dir, t, p, hit, marching, trips, i_final, limit, diag, false);
+    } else {
+        generic_loop(P, dir, t, p, hit, marching, trips, i_final, limit,
+                     [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); });
+    }
+}
+
+template <int GROUP, int PRIM>
+KIFS_DEV V3 shade_hit(const FrameParams& P, V3 p) {
+    if constexpr (GROUP == GROUP_JULIA) return julia_shade(P, p);
+    else
+        return generic_shade(
+            P, p, [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); },
+            [&](V3 q) { return scene_normal<GROUP, PRIM>(P, q); });
+}
+
 // ---- the bunny, four lanes per pixel -------------------------------------------------------
 // The bunny network (kifs.wgsl:84-137) is 3000 instructions per estimate when one lane does it
 // all, and a frame's run time is the longest ray's estimates back to back (a lone wave issues

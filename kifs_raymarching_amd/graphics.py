@@ -309,6 +309,10 @@ class GraphicState:
         check(lib.kifs_render_batch_async(self._ctx, stream, n, cams, ptrs, pitch, y0, y1, encode),
               "render_batch_async")
 
+    def debug_last_round_steps(self) -> int:
+        """Round length of the ray re-queuing in the latest launch (0: one wave per block)."""
+        return int(lib.kifs_debug_last_round_steps(self._ctx))
+
     def set_frames_in_flight(self, n: int):
         """Scheduling hint: the caller keeps n frames in flight on this device (one context and
         stream each).  n > 1 trades the lone-frame residency cap for throughput."""

@@ -89,3 +89,55 @@ def test_bunny_quad_kernel_ragged_frames_and_bands(size, band, heatmap, gs, kifs
     assert got.shape == want.shape == (y1 - y0, size[0], 4)
     assert diff_report(got, want)["mismatched_pixels"] == 0
     assert (want[..., :3] != want[0, 0, :3]).any()
+
+
+@pytest.mark.parametrize("scene", ["julia", "julia_ref", "sierpinski", "torus", "genjulia", "sierpinski_shadow"])
+def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
+    """render_kernel re-queues a workgroup's surviving rays into full waves every 16 / 32 march
+    steps (marches of at least two rounds; not heatmap, not residency-capped lone Julia frames).
+    Long marches on ragged frames and on a band that cuts tiles: every pixel equals the oracle's,
+    i.e. the one-ray-at-a-time march."""
+    FG, PS = kifs.FractalGroup, kifs.PrimitiveShape
+    cam = kifs.CameraData(origin_distance=2.6, phi=0.9, theta=0.35)
+    gui, iters, size = {
+        "julia": (kifs.GuiData(fractal_group=FG.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=200),
+                  (12, 10, 10), (600, 330)),
+        "julia_ref": (kifs.GuiData(fractal_group=FG.JuliaSet, max_iterations=128), (100, 10, 10), (600, 330)),
+        "sierpinski": (kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, max_iterations=200,
+                                    background_color=(3, 20, 60)), (100, 10, 14), (333, 190)),
+        "torus": (kifs.GuiData(primitive_shape=PS.Torus, max_iterations=150), (100, 10, 10), (200, 121)),
+        "genjulia": (kifs.GuiData(fractal_group=FG.GeneralizedJuliaSet, power=4.0, max_iterations=64),
+                     (8, 4, 10), (150, 100)),
+        "sierpinski_shadow": (kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, max_iterations=96),
+                              (100, 10, 10), (160, 120)),
+    }[scene]
+    screen = kifs.ScreenData(*size)
+    W, H = size
+    gs.update_screen_data(screen)
+    gs.set_camera(cam)
+    gs.update_options(gui)
+    gs.set_iters(*iters)
+    ext = None
+    if scene == "sierpinski_shadow":
+        gs.set_extensions(soft_shadow=True, shadow_steps=32, shadow_k=8.0, shadow_t0=0.02, shadow_max_t=6.0)
+        ext = oracle.Ext(1, 32, 8.0, 0.02, 6.0)
+    import torch
+    julia = scene.startswith("julia")
+    try:
+        for y0, y1 in [(0, H), (13, H - 21)]:
+            s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cam, gui))
+            want = oracle.render(s, c, o, oracle.iters(*iters), y0=y0, y1=y1, ext=ext)
+            if julia:  # a batch of two is never residency-capped
+                outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+                st = torch.cuda.Stream()
+                gs.render_batch_async(outs, [cam, cam], stream=st, y0=y0, y1=y1)
+                st.synchronize()
+                got = outs[1].cpu().numpy()
+                assert (outs[0].cpu().numpy() == got).all()
+            else:
+                got = gs.render(y0=y0, y1=y1)
+            assert gs.debug_last_round_steps() == (32 if julia else 16), scene
+            assert diff_report(got, want)["mismatched_pixels"] == 0, (scene, y0, y1)
+            assert (want[..., :3] != want[0, 0, :3]).any()
+    finally:
+        gs.set_extensions(soft_shadow=False)
