@@ -232,6 +232,23 @@ KIFS_DEV float cos_(float x) {
     return ((q + 1) & 2) ? -c : c;
 }
 
+// sin_(x) and cos_(x) at once: one range reduction, each kernel evaluated once.  Bit-identical to
+// the two separate calls (same r, same quadrant, same kernels, same selects).
+KIFS_DEV void sincos_(float x, float& s, float& c) {
+    if (!(abs_(x) <= 1048576.0f)) {
+        s = x - x;
+        c = x - x;
+        return;
+    }
+    float r;
+    int q = reduce_pio2(x, r);
+    const float sk = sin_kernel(r), ck = cos_kernel(r);
+    const float ss = (q & 1) ? ck : sk;
+    const float cc = (q & 1) ? sk : ck;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // ---- acos ---------------------------------------------------------------------
 KIFS_DEV float asin_poly(float x, float z) {
     float p = 4.2163199048E-2f;

@@ -38,7 +38,8 @@ KIFS_DEV V4 quat_pow(V4 q, float x) {
     V3 n = normalize(V3{q.y, q.z, q.w});
     float pw = pow_(norm, x);
     float a = x * phi;
-    float cs = cos_(a), sn = sin_(a);
+    float cs, sn;
+    sincos_(a, sn, cs);
     return V4{pw * cs, pw * (n.x * sn), pw * (n.y * sn), pw * (n.z * sn)};
 }
 
