@@ -134,3 +134,60 @@ def test_frame_stream_delivers_the_sequence_in_order(world, tmp_path, oracle):
         want = oracle.render(sc, oracle.camera_uniform(3.0, 0.25 * i, 0.2), opt, oracle.iters(100, 10, 6))
         assert (got[i] == want).all(), f"frame {i}"
     assert (got[0] != got[1]).any()
+
+
+def _local_frames_worker(rank, world, port, width, height, steps, outdir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from kifs_raymarching_amd.bands import FrameStream
+
+        sc = O.screen_uniform(width, height)
+        opt = O.options_from_gui(primitive_shape=3, max_iterations=40)
+        # bench.py's default at N > 1: frames stay where they were rendered, 3 buffers (as with
+        # three launches in flight), a step's "frame" is a stack of 2 frames (2 per launch)
+        fs = FrameStream(width, 2 * height, rank, world, "cpu", buffers=3, deliver=False)
+        assert fs.frames(0) is None or len(fs.frames(0)) == 1
+
+        def render_stack(out, step_index):
+            for i in range(2):
+                cam = O.camera_uniform(3.0, 0.2 * (2 * step_index + i), 0.1)
+                out[i * height:(i + 1) * height].copy_(
+                    torch.from_numpy(O.render(sc, cam, opt, O.iters(100, 10, 6), nthreads=1)))
+
+        mine = []
+        for k in range(steps):
+            fs.step(k, render_stack)
+            fs.wait(k)  # no exchange: nothing to wait for, must not block or raise
+            mine.append((fs.frame_index(k), fs.target(k).clone().numpy()))
+        fs.wait_all()
+        np.save(os.path.join(outdir, f"rank{rank}.npy"), np.stack([m[1] for m in mine]))
+        np.save(os.path.join(outdir, f"index{rank}.npy"), np.array([m[0] for m in mine]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_stream_without_delivery_keeps_frames_local(tmp_path, oracle):
+    """deliver=False (bench.py's default at N > 1): no exchange step, every rank keeps the frames
+    it rendered; together the ranks hold the whole sequence exactly once."""
+    world, width, height, steps = 2, 36, 24, 3
+    mp.spawn(_local_frames_worker, args=(world, _free_port(), width, height, steps, str(tmp_path)),
+             nprocs=world, join=True)
+    sc = oracle.screen_uniform(width, height)
+    opt = oracle.options_from_gui(primitive_shape=3, max_iterations=40)
+    seen = set()
+    for rank in range(world):
+        stacks = np.load(tmp_path / f"rank{rank}.npy")
+        index = np.load(tmp_path / f"index{rank}.npy")
+        assert list(index) == [k * world + rank for k in range(steps)]
+        for k in range(steps):
+            for i in range(2):
+                f = 2 * int(index[k]) + i
+                seen.add(f)
+                want = oracle.render(sc, oracle.camera_uniform(3.0, 0.2 * f, 0.1), opt, oracle.iters(100, 10, 6))
+                assert (stacks[k][i * height:(i + 1) * height] == want).all(), (rank, k, i)
+    assert seen == set(range(2 * steps * world))
