@@ -229,6 +229,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->tile_cost = nullptr;
     P->counters = c->d_counters;
     P->workgroups_per_cu = 0;
+    P->group_tiles = 1;
     return KIFS_OK;
 }
 
@@ -474,6 +475,21 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     // a residency-capped launch is a lone frame bound by its longest rays: re-queuing helps
     // throughput, not that (1080p Julia: 0.143 ms without, 0.146 ms with)
     if (P.workgroups_per_cu >= 1) P.round_steps = 0;
+    {   // Tiles per workgroup on the re-queuing path.  One tile's queue is short for most of its life
+        // (1080p Julia: mean 100 rays, four rounds in ten with <= 16), two neighbours of the cost order
+        // fill each other's waves: batched 1080p Julia 0.319 -> 0.281 ms, Sierpinski +4 %.  A lone
+        // frame loses instead (4096^2: 0.441 -> 0.465 ms): its heaviest workgroup sets the frame time
+        // and now has twice the rays; 8K KIFS frames have tiles enough to gain (+3 %).  Four tiles per
+        // workgroup need 54 KB of LDS and lose everywhere.  KIFS_GROUP_TILES overrides.
+        static const int forced = [] {
+            const char* e = std::getenv("KIFS_GROUP_TILES");
+            return e ? int(std::strtol(e, nullptr, 10)) : 0;
+        }();
+        const bool kifs_big = c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS) && tt->count >= 65536u;
+        // (the generalised Julia's few, very long workgroups lose 7 % when paired)
+        const bool genjulia = c->options.fractal_group_id == uint32_t(kifs::GROUP_GENJULIA);
+        P.group_tiles = forced > 0 ? forced : (((count > 1 && !genjulia) || kifs_big) ? 2 : 1);
+    }
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
     const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
     if (timed && !hip_ok(hipEventRecord(c->prof_a[pslot], stream), "record(profile start)")) return KIFS_ERR_RUNTIME;

@@ -98,58 +98,141 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
     const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
     uint32_t* const cost_slot = feedback ? &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)] : nullptr;
 
-    if (P.round_steps > 0) {
-        // ---- ray re-queuing --------------------------------------------------------------
-        // Rays of one 8x8 block leave the march at very different steps (measured: 54-66 % of the
-        // lanes of a VALU instruction are live).  So the workgroup keeps its live rays in an LDS
-        // queue and marches in rounds of `round_steps` steps: a round takes the queue's rays 64 at
-        // a time -- full waves -- and every ray ends the round in one of three places: the queue
-        // of the next round, the hit list, or nowhere (a miss keeps the pre-filled background).
-        // Hits are shaded at the end, again 64 at a time.  A ray's own arithmetic is unchanged
-        // (t, and p = fma(t, dir, origin) rebuilt from it exactly as the march itself does), all
-        // rays of the workgroup make their k-th step in the same round (the step counter stays
-        // uniform), and pixels do not interact: same pixels as the one-wave-per-block march.
-        __shared__ uint32_t q_pix[2][BLOCK];
-        __shared__ float q_t[2][BLOCK], q_dx[2][BLOCK], q_dy[2][BLOCK], q_dz[2][BLOCK];
-        __shared__ uint32_t h_pix[BLOCK];
-        __shared__ float h_t[BLOCK], h_dx[BLOCK], h_dy[BLOCK], h_dz[BLOCK];
-        __shared__ uint32_t q_count[2], h_count;
-        if (tid == 0) {
-            q_count[0] = 0;
-            q_count[1] = 0;
-            h_count = 0;
+    // one wave per 8x8 block, every ray from start to finish
+    V3 colour{0.0f, 0.0f, 0.0f};
+    int steps = 0;  // wave-uniform: march steps this wave needed
+    if (!culled && __ballot(valid) != 0ull) {
+        V3 dir = ray_direction(P, x, y);
+        colour = raymarch<GROUP, PRIM>(P, dir, valid, steps);
+    }
+    // cost of this wave for the next frame's tile order: its run time in units of 1024 cycles,
+    // minus a floor that maps culled / instant waves to 0 (march steps alone are too coarse:
+    // hundreds of tiles tie at max_iterations)
+    if (feedback) {
+        const unsigned long long wave_cycles = __builtin_amdgcn_s_memtime() - wave_start;
+        if (lane == 0)
+            s_steps[wave] = int(min(wave_cycles > 4096ull ? (wave_cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
+    }
+    (void)steps;
+    __syncthreads();  // s_srgb and s_steps visible
+    if (tid == 0 && feedback) {  // the tile's slowest wave
+        const int m = max(max(s_steps[0], s_steps[1]), max(s_steps[2], s_steps[3]));
+        if (batch > 1) atomicMax(cost_slot, uint32_t(m));  // the batch's views share the table (the sort clears it)
+        else *cost_slot = uint32_t(m);
+    }
+    uint32_t rgba = P.background_rgba;
+    if (!culled) {
+        uint32_t r, g, b;
+        if (srgb) {
+            r = srgb8(colour.x, s_srgb);
+            g = srgb8(colour.y, s_srgb);
+            b = srgb8(colour.z, s_srgb);
+        } else {
+            r = unorm8(colour.x);
+            g = unorm8(colour.y);
+            b = unorm8(colour.z);
         }
-        s_tile[ly][lx] = P.background_rgba;
-        __syncthreads();
-        {   // round 0's queue: the rays that survive the culls
-            bool alive = false;
-            V3 dir{0.0f, 0.0f, 0.0f};
-            if (!culled && __ballot(valid) != 0ull) {
-                dir = ray_direction(P, x, y);
-                alive = valid && (0 < P.max_iterations) && (0.0f < P.max_distance);
-                if (P.cull_n2 > 0.0f) alive = alive && !ray_never_inside(P, dir);
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
-            if (m != 0ull) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&q_count[0], uint32_t(__builtin_popcountll(m)));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (alive) {
-                    const uint32_t i = base + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
-                    q_pix[0][i] = uint32_t(lx) | (uint32_t(ly) << 8);
-                    q_t[0][i] = 0.0f;
-                    q_dx[0][i] = dir.x;
-                    q_dy[0][i] = dir.y;
-                    q_dz[0][i] = dir.z;
-                }
-            }
+        rgba = r | (g << 8) | (b << 16) | 0xff000000u;  // alpha = 1.0 -> 255
+    }
+    s_tile[ly][lx] = rgba;
+    __syncthreads();
+
+    // store mapping: thread -> (tid & 31, tid >> 5): linear rows of 128 bytes
+    const int sx = tid & (TILE_W - 1), sy = tid >> 5;
+    const int ox = tile_x + sx;
+    const int oy = tile_y + sy;  // row within the band
+    if (ox < P.width && (P.y0 + oy) < P.y1)
+        P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
+}
+
+// render_group_kernel<GROUP, PRIM, T>: the throughput path.  A workgroup renders T consecutive
+// entries of its view's tile order and RE-QUEUES its rays.
+//   Rays of one 8x8 block leave the march at very different steps (one wave per block: 54-66 % of
+//   the lanes of a VALU instruction were live).  So the workgroup keeps its live rays in an LDS
+//   queue and marches in rounds of `round_steps` steps: a round takes the queue's rays 64 at a
+//   time -- full waves -- and every ray ends the round in one of three places: the queue of the
+//   next round, the hit list, or nowhere (a miss keeps the pre-filled background).  Hits are
+//   shaded at the end, again 64 at a time.  T tiles share one queue because a single tile's queue
+//   is short for most of its life (1080p Julia: mean 100 rays, four rounds in ten with <= 16):
+//   neighbours in the cost order have tails of similar length and fill each other's waves.
+//   A ray's own arithmetic is unchanged (t, and p = fma(t, dir, origin) rebuilt from it exactly as
+//   the march itself does), all rays of the workgroup make their k-th step in the same round (the
+//   step counter stays uniform), and pixels do not interact: same pixels as render_kernel.
+template <int GROUP, int PRIM, int T>
+__global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B) {
+    constexpr uint32_t CAP = uint32_t(BLOCK) * T;  // every pixel of the group could be a live ray
+    __shared__ float s_srgb[256];
+    __shared__ uint32_t s_tile[T][TILE_H][TILE_W];
+    __shared__ uint32_t s_tiles[T];  // the group's tiles (x | y << 16), 0xffffffff past the table's end
+    // queue entry: pixel (tile-in-group << 8 | ly << 5 | lx), t, direction
+    __shared__ uint32_t q_pix[2][CAP];
+    __shared__ float q_t[2][CAP], q_dx[2][CAP], q_dy[2][CAP], q_dz[2][CAP];
+    __shared__ uint32_t h_pix[CAP];  // hit list: pixel and t (the direction is recomputed)
+    __shared__ float h_t[CAP];
+    __shared__ uint32_t q_count[2], h_count;
+
+    const uint32_t batch = uint32_t(B.count);
+    const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
+    const uint32_t group = batch > 1 ? blockIdx.x / batch : blockIdx.x;
+    const FrameParams P = batch_frame(B, view);
+    const int tid = threadIdx.x;
+    const bool srgb = (P.encode == 1);
+    if (srgb) s_srgb[tid] = P.srgb_table[tid];
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lx = (wave << 3) | (lane & 7);  // wave w -> 8x8 block w of a tile
+    const int ly = lane >> 3;
+    const bool feedback = P.tile_cost != nullptr;
+    const unsigned long long t_start = feedback ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (tid == 0) {
+        q_count[0] = 0;
+        q_count[1] = 0;
+        h_count = 0;
+    }
+    if (tid < T) {
+        const uint32_t ti = group * uint32_t(T) + uint32_t(tid);
+        s_tiles[tid] = ti < P.tile_count ? P.tile_order[ti] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) s_tile[j][ly][lx] = P.background_rgba;
+    __syncthreads();
+
+    // ---- round 0's queue: the rays that survive the culls
+    for (int j = 0; j < T; ++j) {
+        const uint32_t tile = s_tiles[j];  // uniform
+        if (tile == 0xffffffffu) break;
+        const int x = int(tile & 0xffffu) * TILE_W + lx;
+        const int y = P.y0 + int(tile >> 16) * TILE_H + ly;
+        const bool valid = (x < P.width) && (y < P.y1);
+        if (wave_is_culled(P, x, y, valid) || __ballot(valid) == 0ull) continue;  // wave-uniform
+        const V3 dir = ray_direction(P, x, y);
+        bool alive = valid && (0 < P.max_iterations) && (0.0f < P.max_distance);
+        if (P.cull_n2 > 0.0f) alive = alive && !ray_never_inside(P, dir);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&q_count[0], uint32_t(__builtin_popcountll(m)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (alive) {
+            const uint32_t i = base + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+            q_pix[0][i] = (uint32_t(j) << 8) | (uint32_t(ly) << 5) | uint32_t(lx);
+            q_t[0][i] = 0.0f;
+            q_dx[0][i] = dir.x;
+            q_dy[0][i] = dir.y;
+            q_dz[0][i] = dir.z;
         }
-        __syncthreads();
-        int trips = 0;
-        for (uint32_t cur = 0;; cur ^= 1u) {
-            const uint32_t n = q_count[cur];  // uniform
-            if (n == 0u) break;
-            const uint32_t idx = uint32_t(tid);
+    }
+    __syncthreads();
+
+    // ---- rounds
+    int trips = 0;
+    for (uint32_t cur = 0;; cur ^= 1u) {
+        const uint32_t n = q_count[cur];  // uniform
+        if (n == 0u) break;
+        __syncthreads();  // everyone has read the count
+        if (tid == 0) q_count[cur] = 0;  // queue `cur` is the queue of the round after next
+        const int limit = min(trips + P.round_steps, P.max_iterations);
+        for (uint32_t chunk = uint32_t(wave); chunk * 64u < n; chunk += uint32_t(BLOCK / 64)) {
+            const uint32_t idx = chunk * 64u + uint32_t(lane);
             const bool have = idx < n;
             uint32_t pix = 0;
             float t = 0.0f;
@@ -159,103 +242,56 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
                 t = q_t[cur][idx];
                 dir = V3{q_dx[cur][idx], q_dy[cur][idx], q_dz[cur][idx]};
             }
-            __syncthreads();  // everyone has read queue `cur` and its count
-            if (tid == 0) q_count[cur] = 0;  // it is the queue of the round after next
-            const int limit = min(trips + P.round_steps, P.max_iterations);
-            if (uint32_t(wave) * 64u < n) {  // wave-uniform: this wave has rays
-                // a ray that has advanced has t > 0 (epsilon > 0 on this path), and then its
-                // position is what the march last computed: fma(t, dir, origin)
-                V3 p = (trips == 0) ? P.origin
-                                    : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
-                                         fmaf_(t, dir.z, P.origin.z)};
-                bool hit = false, marching = have;
-                int wave_trips = trips;
-                march_round<GROUP, PRIM>(P, dir, t, p, hit, marching, wave_trips, limit);
-                __builtin_amdgcn_s_setprio(0);
-                const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
-                const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);
-                uint32_t bh = 0, bq = 0;
-                if (lane == 0) {
-                    if (mh) bh = atomicAdd(&h_count, uint32_t(__builtin_popcountll(mh)));
-                    if (mq) bq = atomicAdd(&q_count[cur ^ 1u], uint32_t(__builtin_popcountll(mq)));
-                }
-                bh = __builtin_amdgcn_readfirstlane(bh);
-                bq = __builtin_amdgcn_readfirstlane(bq);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (hit) {
-                    const uint32_t i = bh + uint32_t(__builtin_popcountll(mh & below));
-                    h_pix[i] = pix;
-                    h_t[i] = t;
-                    h_dx[i] = dir.x;
-                    h_dy[i] = dir.y;
-                    h_dz[i] = dir.z;
-                } else if (marching) {
-                    const uint32_t i = bq + uint32_t(__builtin_popcountll(mq & below));
-                    q_pix[cur ^ 1u][i] = pix;
-                    q_t[cur ^ 1u][i] = t;
-                    q_dx[cur ^ 1u][i] = dir.x;
-                    q_dy[cur ^ 1u][i] = dir.y;
-                    q_dz[cur ^ 1u][i] = dir.z;
-                }
+            // a ray that has advanced has t > 0 (epsilon > 0 on this path), and then its position
+            // is what the march last computed: fma(t, dir, origin)
+            V3 p = (trips == 0) ? P.origin
+                                : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                                     fmaf_(t, dir.z, P.origin.z)};
+            bool hit = false, marching = have;
+            int wave_trips = trips;
+            march_round<GROUP, PRIM>(P, dir, t, p, hit, marching, wave_trips, limit);
+            __builtin_amdgcn_s_setprio(0);
+            const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
+            const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);
+            uint32_t bh = 0, bq = 0;
+            if (lane == 0) {
+                if (mh) bh = atomicAdd(&h_count, uint32_t(__builtin_popcountll(mh)));
+                if (mq) bq = atomicAdd(&q_count[cur ^ 1u], uint32_t(__builtin_popcountll(mq)));
             }
-            trips = limit;
-            __syncthreads();  // the next queue and the hit list are complete
-        }
-        {   // shade the hits, 64 to a wave
-            const uint32_t m = h_count;
-            if (uint32_t(tid) < m) {
-                const uint32_t pix = h_pix[tid];
-                const float t = h_t[tid];
-                const V3 dir{h_dx[tid], h_dy[tid], h_dz[tid]};
-                const V3 p = (t == 0.0f) ? P.origin
-                                         : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
-                                              fmaf_(t, dir.z, P.origin.z)};
-                const V3 colour = shade_hit<GROUP, PRIM>(P, p);
-                uint32_t r, g, b;
-                if (srgb) {
-                    r = srgb8(colour.x, s_srgb);
-                    g = srgb8(colour.y, s_srgb);
-                    b = srgb8(colour.z, s_srgb);
-                } else {
-                    r = unorm8(colour.x);
-                    g = unorm8(colour.y);
-                    b = unorm8(colour.z);
-                }
-                s_tile[pix >> 8][pix & 0xffu] = r | (g << 8) | (b << 16) | 0xff000000u;
+            bh = __builtin_amdgcn_readfirstlane(bh);
+            bq = __builtin_amdgcn_readfirstlane(bq);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (hit) {
+                const uint32_t i = bh + uint32_t(__builtin_popcountll(mh & below));
+                h_pix[i] = pix;
+                h_t[i] = t;
+            } else if (marching) {
+                const uint32_t i = bq + uint32_t(__builtin_popcountll(mq & below));
+                q_pix[cur ^ 1u][i] = pix;
+                q_t[cur ^ 1u][i] = t;
+                q_dx[cur ^ 1u][i] = dir.x;
+                q_dy[cur ^ 1u][i] = dir.y;
+                q_dz[cur ^ 1u][i] = dir.z;
             }
         }
-        if (tid == 0 && feedback) {  // cost of the tile: the workgroup's run time
-            const unsigned long long cycles = __builtin_amdgcn_s_memtime() - wave_start;
-            const uint32_t m = uint32_t(min(cycles > 4096ull ? (cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
-            if (batch > 1) atomicMax(cost_slot, m);
-            else *cost_slot = m;
-        }
-        __syncthreads();
-    } else {
-        // ---- one wave per 8x8 block, start to finish (heatmap frames, diagnostics) -----------
-        V3 colour{0.0f, 0.0f, 0.0f};
-        int steps = 0;  // wave-uniform: march steps this wave needed
-        if (!culled && __ballot(valid) != 0ull) {
-            V3 dir = ray_direction(P, x, y);
-            colour = raymarch<GROUP, PRIM>(P, dir, valid, steps);
-        }
-        // cost of this wave for the next frame's tile order: its run time in units of 1024 cycles,
-        // minus a floor that maps culled / instant waves to 0 (march steps alone are too coarse:
-        // hundreds of tiles tie at max_iterations)
-        if (feedback) {
-            const unsigned long long wave_cycles = __builtin_amdgcn_s_memtime() - wave_start;
-            if (lane == 0)
-                s_steps[wave] = int(min(wave_cycles > 4096ull ? (wave_cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
-        }
-        (void)steps;
-        __syncthreads();  // s_srgb and s_steps visible
-        if (tid == 0 && feedback) {  // the tile's slowest wave
-            const int m = max(max(s_steps[0], s_steps[1]), max(s_steps[2], s_steps[3]));
-            if (batch > 1) atomicMax(cost_slot, uint32_t(m));  // the batch's views share the table (the sort clears it)
-            else *cost_slot = uint32_t(m);
-        }
-        uint32_t rgba = P.background_rgba;
-        if (!culled) {
+        trips = limit;
+        __syncthreads();  // the next queue and the hit list are complete
+    }
+
+    // ---- shade the hits, 64 to a wave
+    const uint32_t hits = h_count;  // uniform
+    for (uint32_t i0 = 0; i0 < hits; i0 += uint32_t(BLOCK)) {
+        const uint32_t i = i0 + uint32_t(tid);
+        if (i < hits) {
+            const uint32_t pix = h_pix[i];
+            const float t = h_t[i];
+            const uint32_t tile = s_tiles[pix >> 8];
+            const int hx = int(pix & 31u), hy = int((pix >> 5) & 7u);
+            const V3 dir = ray_direction(P, int(tile & 0xffffu) * TILE_W + hx, P.y0 + int(tile >> 16) * TILE_H + hy);
+            const V3 p = (t == 0.0f) ? P.origin
+                                     : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                                          fmaf_(t, dir.z, P.origin.z)};
+            const V3 colour = shade_hit<GROUP, PRIM>(P, p);
             uint32_t r, g, b;
             if (srgb) {
                 r = srgb8(colour.x, s_srgb);
@@ -266,18 +302,31 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
                 g = unorm8(colour.y);
                 b = unorm8(colour.z);
             }
-            rgba = r | (g << 8) | (b << 16) | 0xff000000u;  // alpha = 1.0 -> 255
+            s_tile[pix >> 8][hy][hx] = r | (g << 8) | (b << 16) | 0xff000000u;
         }
-        s_tile[ly][lx] = rgba;
-        __syncthreads();
     }
+    __syncthreads();
 
-    // store mapping: thread -> (tid & 31, tid >> 5): linear rows of 128 bytes
+    // ---- store: linear rows of 128 bytes; cost of the group's tiles: the workgroup's run time
+    const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
+    uint32_t cost = 0;
+    if (feedback) {
+        const unsigned long long cycles = __builtin_amdgcn_s_memtime() - t_start;
+        cost = uint32_t(min(cycles > 4096ull ? (cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
+    }
     const int sx = tid & (TILE_W - 1), sy = tid >> 5;
-    const int ox = tile_x + sx;
-    const int oy = tile_y + sy;  // row within the band
-    if (ox < P.width && (P.y0 + oy) < P.y1)
-        P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
+    for (int j = 0; j < T; ++j) {
+        const uint32_t tile = s_tiles[j];
+        if (tile == 0xffffffffu) break;
+        const int ox = int(tile & 0xffffu) * TILE_W + sx;
+        const int oy = int(tile >> 16) * TILE_H + sy;  // row within the band
+        if (ox < P.width && (P.y0 + oy) < P.y1) P.out[size_t(oy) * P.pitch_words + ox] = s_tile[j][sy][sx];
+        if (tid == 0 && feedback) {
+            uint32_t* slot = &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)];
+            if (batch > 1) atomicMax(slot, cost);  // the batch's views share the table (the sort clears it)
+            else *slot = cost;
+        }
+    }
 }
 
 // The bunny primitive with four lanes per pixel (see bunny_sdf_quad in kifs_scene.hpp): a
@@ -350,10 +399,10 @@ static unsigned residency_pad_bytes(int workgroups_per_cu) {
         return e ? std::strtol(e, nullptr, 10) : -1L;
     }();
     if (forced >= 0) return unsigned(forced);
-    switch (workgroups_per_cu) {  // static LDS is 18 KiB (ray queues); a CU has 160 KiB
+    switch (workgroups_per_cu) {  // static LDS of render_kernel is 2 KiB; a CU has 160 KiB
     case 1: return 100 * 1024;
-    case 2: return 55 * 1024;
-    case 3: return 34 * 1024;
+    case 2: return 72 * 1024;
+    case 3: return 50 * 1024;
     default: return 0;
     }
 }
@@ -377,6 +426,16 @@ static hipError_t launch_variant(const BatchParams& B, hipStream_t stream) {
             if (attr != hipSuccess) return attr;
             if (dev >= 0 && dev < 64) opted_in[dev] = true;
         }
+    }
+    if (P.round_steps > 0) {  // the throughput path: rays re-queued, one or two tiles per workgroup
+        if (P.group_tiles >= 2) {
+            hipLaunchKernelGGL((render_group_kernel<GROUP, PRIM, 2>), dim3(((P.tile_count + 1u) / 2u) * uint32_t(B.count)),
+                               dim3(BLOCK), 0, stream, B);
+        } else {
+            hipLaunchKernelGGL((render_group_kernel<GROUP, PRIM, 1>), dim3(P.tile_count * uint32_t(B.count)), dim3(BLOCK), 0,
+                               stream, B);
+        }
+        return hipGetLastError();
     }
     hipLaunchKernelGGL((render_kernel<GROUP, PRIM>), dim3(P.tile_count * uint32_t(B.count)), dim3(BLOCK), pad, stream, B);
     return hipGetLastError();

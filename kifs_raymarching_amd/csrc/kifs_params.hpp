@@ -59,6 +59,7 @@ struct FrameParams {
     // Ray re-queuing (render_kernel): march steps per round between two re-packings of the
     // workgroup's surviving rays into full waves; 0 = every wave marches its own 64 pixels to the end.
     int round_steps;
+    int group_tiles;                    // tiles (consecutive entries of the order) per workgroup of that path: 1 or 2
     // Host-side launch hint, not read by the kernels: how many workgroups may share a CU
     // (0 = no cap).  See residency_for() in kifs_api.cpp.
     int workgroups_per_cu;
