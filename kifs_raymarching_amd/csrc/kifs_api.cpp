@@ -201,8 +201,8 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
         P->quick_cull_n2 = (sane && !o.is_heatmap && o.max_iterations > 0) ? 1.2f * R * R : 0.0f;
         P->inv_height = 1.0f / c->screen.height;
     }
-    {   // Ray re-queuing (render_kernel): rounds of this many march steps -- 32 for the Julia
-        // pipeline, 16 for the others (measured; KIFS_ROUND_STEPS overrides, 0 switches it off).
+    {   // Ray re-queuing (render_group_kernel): rounds of this many march steps -- 16 for the Julia
+        // pipeline, 8 for the others (measured; KIFS_ROUND_STEPS overrides, 0 switches it off).
         // Not for heatmap frames (their per-ray step count is kept by the one-wave-per-block
         // march), not with a non-positive epsilon (the queue rebuilds p from t and relies on
         // t > 0 after a step), not for marches too short to repay the rounds' barriers.
@@ -210,7 +210,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
             const char* e = std::getenv("KIFS_ROUND_STEPS");
             return e ? int(std::strtol(e, nullptr, 10)) : -1;
         }();
-        int rounds = forced >= 0 ? forced : (o.fractal_group_id == uint32_t(kifs::GROUP_JULIA) ? 32 : 16);
+        int rounds = forced >= 0 ? forced : (o.fractal_group_id == uint32_t(kifs::GROUP_JULIA) ? 16 : 8);
         if (o.is_heatmap || !(o.epsilon > 0.0f) || o.max_iterations < 2 * rounds) rounds = 0;
         P->round_steps = rounds;
     }
@@ -475,6 +475,9 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     // a residency-capped launch is a lone frame bound by its longest rays: re-queuing helps
     // throughput, not that (1080p Julia: 0.143 ms without, 0.146 ms with)
     if (P.workgroups_per_cu >= 1) P.round_steps = 0;
+    // nor does a launch too small to fill the device twice over (256x256 x 8 views = 2048
+    // workgroups: 0.038 ms without, 0.062 ms with)
+    if (uint64_t(tt->count) * uint64_t(count) < 4096u) P.round_steps = 0;
     {   // Tiles per workgroup on the re-queuing path.  One tile's queue is short for most of its life
         // (1080p Julia: mean 100 rays, four rounds in ten with <= 16), two neighbours of the cost order
         // fill each other's waves: batched 1080p Julia 0.319 -> 0.281 ms, Sierpinski +4 %.  A lone

@@ -93,23 +93,24 @@ def test_bunny_quad_kernel_ragged_frames_and_bands(size, band, heatmap, gs, kifs
 
 @pytest.mark.parametrize("scene", ["julia", "julia_ref", "sierpinski", "torus", "genjulia", "sierpinski_shadow"])
 def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
-    """render_kernel re-queues a workgroup's surviving rays into full waves every 16 / 32 march
+    """render_group_kernel re-queues a workgroup's surviving rays into full waves every 8 / 16 march
     steps (marches of at least two rounds; not heatmap, not residency-capped lone Julia frames).
-    Long marches on ragged frames and on a band that cuts tiles: every pixel equals the oracle's,
-    i.e. the one-ray-at-a-time march."""
+    Long marches on a ragged frame of more than 4096 tiles (smaller launches keep one wave per
+    block) and on a band that cuts tiles: every pixel equals the oracle's, i.e. the
+    one-ray-at-a-time march."""
     FG, PS = kifs.FractalGroup, kifs.PrimitiveShape
     cam = kifs.CameraData(origin_distance=2.6, phi=0.9, theta=0.35)
     gui, iters, size = {
         "julia": (kifs.GuiData(fractal_group=FG.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=200),
-                  (12, 10, 10), (600, 330)),
-        "julia_ref": (kifs.GuiData(fractal_group=FG.JuliaSet, max_iterations=128), (100, 10, 10), (600, 330)),
+                  (12, 10, 10), (1030, 1040)),
+        "julia_ref": (kifs.GuiData(fractal_group=FG.JuliaSet, max_iterations=128), (100, 10, 10), (1030, 1040)),
         "sierpinski": (kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, max_iterations=200,
-                                    background_color=(3, 20, 60)), (100, 10, 14), (333, 190)),
-        "torus": (kifs.GuiData(primitive_shape=PS.Torus, max_iterations=150), (100, 10, 10), (200, 121)),
+                                    background_color=(3, 20, 60)), (100, 10, 14), (1030, 1040)),
+        "torus": (kifs.GuiData(primitive_shape=PS.Torus, max_iterations=150), (100, 10, 10), (1030, 1040)),
         "genjulia": (kifs.GuiData(fractal_group=FG.GeneralizedJuliaSet, power=4.0, max_iterations=64),
-                     (8, 4, 10), (150, 100)),
+                     (8, 4, 10), (1030, 1040)),
         "sierpinski_shadow": (kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, max_iterations=96),
-                              (100, 10, 10), (160, 120)),
+                              (100, 10, 10), (1030, 1040)),
     }[scene]
     screen = kifs.ScreenData(*size)
     W, H = size
@@ -136,7 +137,7 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
                 assert (outs[0].cpu().numpy() == got).all()
             else:
                 got = gs.render(y0=y0, y1=y1)
-            assert gs.debug_last_round_steps() == (32 if julia else 16), scene
+            assert gs.debug_last_round_steps() == (16 if julia else 8), scene
             assert diff_report(got, want)["mismatched_pixels"] == 0, (scene, y0, y1)
             assert (want[..., :3] != want[0, 0, :3]).any()
     finally:
