@@ -274,6 +274,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = elapsed * 1e3  # this rank's wall time between the two synchronisation points
+    # which kernel the launches used: the re-queuing throughput kernel or the one-wave-per-block one
+    bunny = int(w.gui.fractal_group) == 0 and int(w.gui.primitive_shape) == 5
+    kernel_name = ("render_bunny_quad_kernel" if bunny else
+                   "render_group_kernel" if gss[0].debug_last_round_steps() > 0 else "render_kernel")
     reads = [g.profile_read() for g in gss]
     timed_launches = sum(r[0] for r in reads)
     kernel_mean_ms = sum(r[0] * r[1] for r in reads) / max(timed_launches, 1)
@@ -343,7 +347,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic(key, B) if world == 1 else None,
-                         "kernel": "render_kernel", "kernel_ms": round(launch_s * 1e3, 5),
+                         "kernel": kernel_name, "kernel_ms": round(launch_s * 1e3, 5),
                          "kernel_ms_min": round(kernel_min_ms, 5), "kernel_ms_max": round(kernel_max_ms, 5),
                          "launches_timed": timed_launches,
                          "concurrent_launches": F,
