@@ -169,7 +169,9 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     __shared__ float q_t[2][CAP], q_dx[2][CAP], q_dy[2][CAP], q_dz[2][CAP];
     __shared__ uint32_t h_pix[CAP];  // hit list: pixel and t (the direction is recomputed)
     __shared__ float h_t[CAP];
-    __shared__ uint32_t q_count[2], h_count;
+    // three counters for two buffers: round r reads count[r % 3], appends under count[(r + 1) % 3] and
+    // clears count[(r + 2) % 3], which nobody else touches in that round -- one barrier per round
+    __shared__ uint32_t q_count[3], h_count;
 
     const uint32_t batch = uint32_t(B.count);
     const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     if (tid == 0) {
         q_count[0] = 0;
         q_count[1] = 0;
+        q_count[2] = 0;
         h_count = 0;
     }
     if (tid < T) {
@@ -225,11 +228,11 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
 
     // ---- rounds
     int trips = 0;
-    for (uint32_t cur = 0;; cur ^= 1u) {
-        const uint32_t n = q_count[cur];  // uniform
+    for (uint32_t cur = 0, cnt = 0;; cur ^= 1u, cnt = (cnt + 1u) % 3u) {
+        const uint32_t n = q_count[cnt];  // uniform
         if (n == 0u) break;
-        __syncthreads();  // everyone has read the count
-        if (tid == 0) q_count[cur] = 0;  // queue `cur` is the queue of the round after next
+        const uint32_t cnt_next = (cnt + 1u) % 3u;
+        if (tid == 0) q_count[(cnt + 2u) % 3u] = 0;  // the counter of the round after next
         const int limit = min(trips + P.round_steps, P.max_iterations);
         for (uint32_t chunk = uint32_t(wave); chunk * 64u < n; chunk += uint32_t(BLOCK / 64)) {
             const uint32_t idx = chunk * 64u + uint32_t(lane);
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             uint32_t bh = 0, bq = 0;
             if (lane == 0) {
                 if (mh) bh = atomicAdd(&h_count, uint32_t(__builtin_popcountll(mh)));
-                if (mq) bq = atomicAdd(&q_count[cur ^ 1u], uint32_t(__builtin_popcountll(mq)));
+                if (mq) bq = atomicAdd(&q_count[cnt_next], uint32_t(__builtin_popcountll(mq)));
             }
             bh = __builtin_amdgcn_readfirstlane(bh);
             bq = __builtin_amdgcn_readfirstlane(bq);
