@@ -3,16 +3,19 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A "step" is one frame of the workload per rank: one launch of the HIP render kernel over
-the frame.  At N > 1 (one process per GPU, launched by torch.distributed.run) the default
-is frame-parallel: in each step every rank renders one whole frame of the sequence and the
-finished frames are delivered to rank 0 by grouped RCCL point-to-point transfers over xGMI
-(weak scaling: per-GPU work is fixed, value = N x pixels per step / time).  `--shard bands`
-instead splits every frame into row bands gathered into rank 0's frame (strong scaling of
-one frame: the low-latency mode; it cannot raise throughput much because every band still
-contains the frame's longest rays -- DESIGN.md section 6).  The default workload is
-BASELINE.json's metric configuration: 1920x1080 quaternion-Julia, 256 march steps, 12 SDF
-iterations.  Rank 0 prints ONE JSON line.
+A "step" is one launch of the render path per rank over its batch of synthetic input:
+`--frames-per-launch` frames of the workload's sequence (default 8, one camera and one
+destination each; 1 = the lone-frame latency path), rendered by one kifs_render_batch_async
+call.  At N > 1 (one process per GPU, launched by torch.distributed.run) the default is
+frame-parallel: in step k rank r renders frames (k N + r) B .. + B - 1 of the sequence.
+Frames are independent units, so there is no exchange step: each frame stays in the HBM of
+the GPU that rendered it (weak scaling: per-GPU work is fixed, value = N x B x pixels per
+step / time); `--deliver root` ships the finished frames to rank 0 by grouped RCCL
+point-to-point transfers over xGMI instead.  `--shard bands` splits every frame into row
+bands gathered into rank 0's frame (strong scaling of one frame: the low-latency mode; it
+cannot raise throughput much because every band still contains the frame's longest rays --
+DESIGN.md section 6).  The default workload is BASELINE.json's metric configuration:
+1920x1080 quaternion-Julia, 256 march steps, 12 SDF iterations.  Rank 0 prints ONE JSON line.
 
 There are no HBM-resident inputs beyond the 156 uniform bytes; the output frame lives in
 HBM (torch tensor) and is written by the kernel.  `roofline` prices the dominant kernel
