@@ -436,9 +436,15 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
             return KIFS_ERR_RUNTIME;
     }
     if (use_feedback) tt->last_stream = stream;
-    // a batch is launched with the sort in its own stream and refreshes every other launch: its
-    // launches are long, its views move (an orbit), and the device is full anyway
-    const uint64_t period = count > 1 ? 2 : FEEDBACK_PERIOD;
+    // a batch is launched with the sort in its own stream and refreshes every third launch (its
+    // launches are long and its views move: an orbit; measured best for fixed and moving cameras;
+    // KIFS_BATCH_PERIOD overrides)
+    static const uint64_t BATCH_PERIOD = [] {
+        const char* e = std::getenv("KIFS_BATCH_PERIOD");
+        long v = e ? std::strtol(e, nullptr, 10) : 3;
+        return uint64_t(v < 2 ? 2 : v);
+    }();
+    const uint64_t period = count > 1 ? BATCH_PERIOD : FEEDBACK_PERIOD;
     const uint64_t k = use_feedback ? tt->launches % period : 0;
     // With several frames in flight (several contexts and streams on one device) the sort runs
     // in the launch stream itself: streams share a handful of hardware queues, and an event wait
