@@ -481,6 +481,10 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     // a residency-capped launch is a lone frame bound by its longest rays: re-queuing helps
     // throughput, not that (1080p Julia: 0.143 ms without, 0.146 ms with)
     if (P.workgroups_per_cu >= 1) P.round_steps = 0;
+    // (an uncapped lone Julia frame -- 4096^2 -- prefers longer rounds: 0.430 ms at 32 steps, 0.445 at 16)
+    if (P.round_steps == 16 && count == 1 && c->options.fractal_group_id == uint32_t(kifs::GROUP_JULIA) &&
+        P.max_iterations >= 64 && std::getenv("KIFS_ROUND_STEPS") == nullptr)
+        P.round_steps = 32;
     // nor does a launch too small to fill the device twice over (256x256 x 8 views = 2048
     // workgroups: 0.038 ms without, 0.062 ms with)
     if (uint64_t(tt->count) * uint64_t(count) < 4096u) P.round_steps = 0;
