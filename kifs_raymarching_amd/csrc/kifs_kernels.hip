@@ -1,21 +1,22 @@
 // kifs_kernels.hip -- gfx950 kernels of the raymarching library and their launchers.
 //
-// render_kernel<GROUP, PRIM>: one thread per pixel, 256-thread workgroups.
-//   * A workgroup owns a 32 x 8 pixel tile; each of its 4 waves owns an 8 x 8
-//     sub-tile, so the 64 rays of a wave are spatially compact and drop out of the
-//     march loop at similar times (wave time = slowest lane).
-//   * Frame constants arrive as the kernel argument (scalar loads -> SGPRs); the
-//     256-entry sRGB threshold table is staged into LDS once per workgroup.
-//   * Encoded pixels go through an LDS tile so that the global store is linear:
-//     every wave-level store instruction writes two full 128-byte row segments.
-//   * The frame's run time is set by its longest rays (a lone wave pays ~5 cycles per
-//     instruction whatever else the chip does), so workgroups take their tile from a
-//     host-built order table, nearest-to-the-image-centre first: the camera always looks
-//     at the world origin (data.rs:115-129), where every scene of the reference sits, so
-//     the rays that march longest start at t = 0 instead of behind thousands of cheap
-//     background tiles.  Neighbouring entries of the table are dealt round-robin over the
-//     8 XCDs by the dispatcher, which spreads the expensive centre evenly; there is no
-//     inter-workgroup data, so placement only affects speed.
+// Three render kernels, all 256-thread workgroups over 32 x 8 pixel tiles taken from a tile ORDER
+// table, all fed by the kernel argument (BatchParams: frame constants + up to 8 views; scalar loads ->
+// SGPRs), all storing encoded pixels through an LDS tile so that every wave-level store instruction
+// writes two full 128-byte row segments:
+//   render_kernel<GROUP, PRIM>          the latency path: each wave owns an 8 x 8 block of its tile and
+//                                       marches its 64 rays from start to finish (lone frames, heatmap
+//                                       frames, diagnostics, small launches)
+//   render_group_kernel<GROUP, PRIM, T> the throughput path: the rays of T tiles share an LDS queue and
+//                                       are re-packed into full waves every few march steps
+//   render_bunny_quad_kernel            the bunny primitive, four lanes per pixel
+// Tile order: a frame's run time is set by its longest rays (a lone wave pays ~5 cycles per
+// instruction whatever else the chip does), so workgroups start with the expensive tiles --
+// nearest-to-the-image-centre first on a geometry's first launches (the camera always looks at
+// the world origin, data.rs:115-129, where every scene of the reference sits), then by the
+// per-tile run times the launches themselves record (tile_order_kernel).  Neighbouring entries of
+// the table are dealt round-robin over the 8 XCDs by the dispatcher, which spreads the expensive
+// tiles evenly; there is no inter-workgroup data, so placement only affects speed.
 //
 // Replaces: vs_main + rasteriser + fs_main + ROP of the reference
 // (src/shaders/dependencies/entry.wgsl:35-59, src/render/graphics.rs:310-325,

@@ -665,7 +665,7 @@ struct JuliaDiag {  // diagnostics of one wave's march (SGPRs)
 // re-queues its rays).  State in, state out; i_final is the heatmap's loop counter.
 template <bool SHORT_DIVSQRT>
 KIFS_DEV void julia_loop(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit, bool& marching,
-                         int& trips, int& i_final, int limit, JuliaDiag& diag, bool stamp) {
+                         int& trips, int& i_final, int limit, JuliaDiag& diag) {
     const bool fast_ok = (P.is_heatmap == 0u) && (P.sdf_iters >= 1);  // wave-uniform
     for (;;) {
         const unsigned long long live = __builtin_amdgcn_ballot_w64(marching);
@@ -746,7 +746,7 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
     JuliaDiag diag;
     const bool stamp = P.counters != nullptr;
     const unsigned long long wave_t0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-    julia_loop<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, i_final, P.max_iterations, diag, stamp);
+    julia_loop<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, i_final, P.max_iterations, diag);
     __builtin_amdgcn_s_setprio(0);
     steps = trips;
     if (__builtin_expect(stamp, 0)) {
@@ -860,7 +860,7 @@ KIFS_DEV void march_round(const FrameParams& P, V3 dir, float& t, V3& p, bool& h
     int i_final = 0;  // heatmap frames do not take this path
     if constexpr (GROUP == GROUP_JULIA) {
         JuliaDiag diag;
-        julia_loop<PRIM == 1>(P, dir, t, p, hit, marching, trips, i_final, limit, diag, false);
+        julia_loop<PRIM == 1>(P, dir, t, p, hit, marching, trips, i_final, limit, diag);
     } else {
         generic_loop(P, dir, t, p, hit, marching, trips, i_final, limit,
                      [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); });
