@@ -279,8 +279,8 @@ def main():
     dev_ms = elapsed * 1e3  # this rank's wall time between the two synchronisation points
     # which kernel the launches used: the re-queuing throughput kernel or the one-wave-per-block one
     bunny = int(w.gui.fractal_group) == 0 and int(w.gui.primitive_shape) == 5
-    kernel_name = ("render_bunny_quad_kernel" if bunny else
-                   "render_group_kernel" if gss[0].debug_last_round_steps() > 0 else "render_kernel")
+    kernel_name = ("render_group_kernel" if gss[0].debug_last_round_steps() > 0 else
+                   "render_bunny_quad_kernel" if bunny else "render_kernel")
     reads = [g.profile_read() for g in gss]
     timed_launches = sum(r[0] for r in reads)
     kernel_mean_ms = sum(r[0] * r[1] for r in reads) / max(timed_launches, 1)

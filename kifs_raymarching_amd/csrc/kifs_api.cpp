@@ -485,6 +485,10 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     if (P.round_steps == 16 && count == 1 && c->options.fractal_group_id == uint32_t(kifs::GROUP_JULIA) &&
         P.max_iterations >= 64 && std::getenv("KIFS_ROUND_STEPS") == nullptr)
         P.round_steps = 32;
+    // (nor does the lone bunny frame: 0.461 ms with the quad kernel, 0.670 ms in rounds)
+    const bool bunny_scene = c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS) &&
+                             c->options.primitive_id == uint32_t(kifs::PRIM_BUNNY);
+    if (bunny_scene && count == 1) P.round_steps = 0;
     // nor does a launch too small to fill the device twice over (256x256 x 8 views = 2048
     // workgroups: 0.038 ms without, 0.062 ms with)
     if (uint64_t(tt->count) * uint64_t(count) < 4096u) P.round_steps = 0;
@@ -501,13 +505,13 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         const bool kifs_big = c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS) && tt->count >= 65536u;
         // (the generalised Julia's few, very long workgroups lose 7 % when paired)
         const bool genjulia = c->options.fractal_group_id == uint32_t(kifs::GROUP_GENJULIA);
-        P.group_tiles = forced > 0 ? forced : (((count > 1 && !genjulia) || kifs_big) ? 2 : 1);
+        // (nor the bunny: its 216 VGPRs allow two workgroups per CU either way, pairs just run longer)
+        P.group_tiles = forced > 0 ? forced : ((((count > 1 && !genjulia) || kifs_big) && !bunny_scene) ? 2 : 1);
     }
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
     const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
     if (timed && !hip_ok(hipEventRecord(c->prof_a[pslot], stream), "record(profile start)")) return KIFS_ERR_RUNTIME;
-    c->last_round_steps = (c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS) &&
-                           c->options.primitive_id == uint32_t(kifs::PRIM_BUNNY)) ? 0 : P.round_steps;
+    c->last_round_steps = P.round_steps;
     hipError_t e = kifs::launch_render(B, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
     if (!hip_ok(e, "render_kernel launch")) return KIFS_ERR_RUNTIME;

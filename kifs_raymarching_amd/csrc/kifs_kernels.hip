@@ -162,6 +162,11 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
 template <int GROUP, int PRIM, int T>
 __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B) {
     constexpr uint32_t CAP = uint32_t(BLOCK) * T;  // every pixel of the group could be a live ray
+    // lanes per ray in the march: 4 for the bunny (bunny_sdf_quad: one network column group per lane,
+    // a wave then carries 16 rays), 1 otherwise.  Set-up is one lane per pixel either way.
+    constexpr bool BUNNY = (GROUP == GROUP_KIFS && PRIM == PRIM_BUNNY);
+    constexpr uint32_t LPR = BUNNY ? 4u : 1u;
+    constexpr uint32_t RAYS = 64u / LPR;  // rays per wave and chunk
     __shared__ float s_srgb[256];
     __shared__ uint32_t s_tile[T][TILE_H][TILE_W];
     __shared__ uint32_t s_tiles[T];  // the group's tiles (x | y << 16), 0xffffffff past the table's end
@@ -228,6 +233,8 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     __syncthreads();
 
     // ---- rounds
+    BunnyQuad W;  // (bunny only) this lane's column group of the network, loaded with the wave's first rays
+    bool weights_loaded = false;
     int trips = 0;
     for (uint32_t cur = 0, cnt = 0;; cur ^= 1u, cnt = (cnt + 1u) % 3u) {
         const uint32_t n = q_count[cnt];  // uniform
@@ -235,9 +242,10 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
         const uint32_t cnt_next = (cnt + 1u) % 3u;
         if (tid == 0) q_count[(cnt + 2u) % 3u] = 0;  // the counter of the round after next
         const int limit = min(trips + P.round_steps, P.max_iterations);
-        for (uint32_t chunk = uint32_t(wave); chunk * 64u < n; chunk += uint32_t(BLOCK / 64)) {
-            const uint32_t idx = chunk * 64u + uint32_t(lane);
+        for (uint32_t chunk = uint32_t(wave); chunk * RAYS < n; chunk += uint32_t(BLOCK / 64)) {
+            const uint32_t idx = chunk * RAYS + uint32_t(lane) / LPR;  // the LPR lanes of a ray hold the same state
             const bool have = idx < n;
+            const bool leader = (uint32_t(lane) % LPR) == 0u;      // the lane that files the ray afterwards
             uint32_t pix = 0;
             float t = 0.0f;
             V3 dir{0.0f, 0.0f, 1.0f};
@@ -253,10 +261,20 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
                                      fmaf_(t, dir.z, P.origin.z)};
             bool hit = false, marching = have;
             int wave_trips = trips;
-            march_round<GROUP, PRIM>(P, dir, t, p, hit, marching, wave_trips, limit);
+            if constexpr (BUNNY) {
+                if (!weights_loaded) {  // wave-uniform: first chunk of this wave
+                    bunny_quad_load(W, lane & 3);
+                    weights_loaded = true;
+                }
+                int i_final = 0;
+                generic_loop(P, dir, t, p, hit, marching, wave_trips, i_final, limit,
+                             [&](V3 q, unsigned long long) { return bunny_sdf_quad(W, q); });
+            } else {
+                march_round<GROUP, PRIM>(P, dir, t, p, hit, marching, wave_trips, limit);
+            }
             __builtin_amdgcn_s_setprio(0);
-            const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
-            const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);
+            const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit && leader);
+            const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching && leader);
             uint32_t bh = 0, bq = 0;
             if (lane == 0) {
                 if (mh) bh = atomicAdd(&h_count, uint32_t(__builtin_popcountll(mh)));
@@ -265,11 +283,11 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             bh = __builtin_amdgcn_readfirstlane(bh);
             bq = __builtin_amdgcn_readfirstlane(bq);
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (hit) {
+            if (hit && leader) {
                 const uint32_t i = bh + uint32_t(__builtin_popcountll(mh & below));
                 h_pix[i] = pix;
                 h_t[i] = t;
-            } else if (marching) {
+            } else if (marching && leader) {
                 const uint32_t i = bq + uint32_t(__builtin_popcountll(mq & below));
                 q_pix[cur ^ 1u][i] = pix;
                 q_t[cur ^ 1u][i] = t;
@@ -284,8 +302,11 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
 
     // ---- shade the hits, 64 to a wave
     const uint32_t hits = h_count;  // uniform
-    for (uint32_t i0 = 0; i0 < hits; i0 += uint32_t(BLOCK)) {
-        const uint32_t i = i0 + uint32_t(tid);
+    if constexpr (BUNNY) {
+        if (hits != 0u && !weights_loaded) bunny_quad_load(W, lane & 3);  // a wave that marched nothing shades too
+    }
+    for (uint32_t i0 = 0; i0 < hits; i0 += uint32_t(BLOCK) / LPR) {
+        const uint32_t i = i0 + uint32_t(tid) / LPR;
         if (i < hits) {
             const uint32_t pix = h_pix[i];
             const float t = h_t[i];
@@ -295,7 +316,14 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             const V3 p = (t == 0.0f) ? P.origin
                                      : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
                                           fmaf_(t, dir.z, P.origin.z)};
-            const V3 colour = shade_hit<GROUP, PRIM>(P, p);
+            V3 colour;
+            if constexpr (BUNNY) {
+                colour = generic_shade(
+                    P, p, [&](V3 q, unsigned long long) { return bunny_sdf_quad(W, q); },
+                    [&](V3 q) { return normal_fd(P.epsilon, q, [&](V3 u) { return bunny_sdf_quad(W, u); }); });
+            } else {
+                colour = shade_hit<GROUP, PRIM>(P, p);
+            }
             uint32_t r, g, b;
             if (srgb) {
                 r = srgb8(colour.x, s_srgb);
@@ -306,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
                 g = unorm8(colour.y);
                 b = unorm8(colour.z);
             }
-            s_tile[pix >> 8][hy][hx] = r | (g << 8) | (b << 16) | 0xff000000u;
+            if ((uint32_t(tid) % LPR) == 0u) s_tile[pix >> 8][hy][hx] = r | (g << 8) | (b << 16) | 0xff000000u;
         }
     }
     __syncthreads();
@@ -446,6 +474,17 @@ static hipError_t launch_variant(const BatchParams& B, hipStream_t stream) {
 }
 
 static hipError_t launch_bunny_quad(const BatchParams& B, hipStream_t stream) {
+    const FrameParams& P = B.frame;
+    if (P.round_steps > 0) {  // the throughput path: re-queued rays, four lanes per ray
+        if (P.group_tiles >= 2) {
+            hipLaunchKernelGGL((render_group_kernel<GROUP_KIFS, PRIM_BUNNY, 2>),
+                               dim3(((P.tile_count + 1u) / 2u) * uint32_t(B.count)), dim3(BLOCK), 0, stream, B);
+        } else {
+            hipLaunchKernelGGL((render_group_kernel<GROUP_KIFS, PRIM_BUNNY, 1>), dim3(P.tile_count * uint32_t(B.count)),
+                               dim3(BLOCK), 0, stream, B);
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(render_bunny_quad_kernel, dim3(B.frame.tile_count * 4u * uint32_t(B.count)), dim3(BLOCK), 0,
                        stream, B);
     return hipGetLastError();

@@ -91,7 +91,8 @@ def test_bunny_quad_kernel_ragged_frames_and_bands(size, band, heatmap, gs, kifs
     assert (want[..., :3] != want[0, 0, :3]).any()
 
 
-@pytest.mark.parametrize("scene", ["julia", "julia_ref", "sierpinski", "torus", "genjulia", "sierpinski_shadow"])
+@pytest.mark.parametrize("scene", ["julia", "julia_ref", "sierpinski", "torus", "genjulia", "sierpinski_shadow",
+                                   "bunny", "bunny_shadow"])
 def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
     """render_group_kernel re-queues a workgroup's surviving rays into full waves every 8 / 16 march
     steps (marches of at least two rounds; not heatmap, not residency-capped lone Julia frames).
@@ -111,6 +112,10 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
                      (8, 4, 10), (1030, 1040)),
         "sierpinski_shadow": (kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, max_iterations=96),
                               (100, 10, 10), (1030, 1040)),
+        # the bunny takes the re-queuing path on batched launches only, four lanes per ray
+        "bunny": (kifs.GuiData(primitive_shape=PS.Bunny, max_iterations=64, fractal_color=(240, 200, 90)),
+                  (100, 10, 10), (1030, 1032)),
+        "bunny_shadow": (kifs.GuiData(primitive_shape=PS.Bunny, max_iterations=48), (100, 10, 10), (1030, 1040)),
     }[scene]
     screen = kifs.ScreenData(*size)
     W, H = size
@@ -119,16 +124,20 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
     gs.update_options(gui)
     gs.set_iters(*iters)
     ext = None
-    if scene == "sierpinski_shadow":
+    if scene.endswith("_shadow"):
         gs.set_extensions(soft_shadow=True, shadow_steps=32, shadow_k=8.0, shadow_t0=0.02, shadow_max_t=6.0)
         ext = oracle.Ext(1, 32, 8.0, 0.02, 6.0)
     import torch
     julia = scene.startswith("julia")
+    batched = julia or scene.startswith("bunny")
+    if scene.startswith("bunny"):
+        cam = kifs.CameraData(origin_distance=2.2, phi=0.9, theta=0.35)
+        gs.set_camera(cam)
     try:
         for y0, y1 in [(0, H), (13, H - 21)]:
             s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cam, gui))
             want = oracle.render(s, c, o, oracle.iters(*iters), y0=y0, y1=y1, ext=ext)
-            if julia:  # a batch of two is never residency-capped
+            if batched:  # a batch of two is never residency-capped
                 outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
                 st = torch.cuda.Stream()
                 gs.render_batch_async(outs, [cam, cam], stream=st, y0=y0, y1=y1)
