@@ -237,10 +237,6 @@ int kifs_abi_version(void);
  * (xyz triples, host pointers) on the device.  Either output may be NULL. */
 int kifs_eval_points(kifs_ctx* ctx, const float* points_xyz, int n, float* sdf_out,
                      float* normal_out_xyz);
-/* Sierpinski estimates through the two-rays-per-lane fold of the throughput path: point i shares a
- * lane with point i ^ 1 (even = ray A, odd = ray B).  mode 1: every ray live; mode 2: in every third
- * pair ray B is dead (sdf_out of that point is then unspecified).  For tests. */
-int kifs_debug_eval_sierpinski_pairs(kifs_ctx* ctx, const float* points_xyz, int n, float* sdf_out, int mode);
 
 /* Evaluates one of the library's f32 elementary functions on the device over
  * `n` host values.  fn: 0 log, 1 log2, 2 exp2, 3 sin, 4 cos, 5 acos,

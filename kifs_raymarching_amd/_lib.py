@@ -96,7 +96,6 @@ SIGNATURES = {
     "kifs_strerror": (C.c_char_p, [C.c_int]),
     "kifs_abi_version": (C.c_int, []),
     "kifs_eval_points": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, _f32p]),
-    "kifs_debug_eval_sierpinski_pairs": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, C.c_int]),
     "kifs_debug_counters": (C.c_int, [_ctx, C.c_int, _P(C.c_uint64)]),
     "kifs_debug_get_tile_order": (C.c_int, [_ctx, _P(C.c_uint32), C.c_size_t, _P(C.c_size_t)]),
     "kifs_debug_set_tile_order": (C.c_int, [_ctx, _P(C.c_uint32), C.c_size_t]),

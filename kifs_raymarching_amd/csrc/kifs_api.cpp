@@ -878,7 +878,7 @@ int kifs_debug_wave_records(kifs_ctx* c, unsigned long long* out, size_t max_wav
     return KIFS_OK;
 }
 
-static int eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float* nrm_out, int paired) {
+int kifs_eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float* nrm_out) {
     if (!c || !pts || n < 0) return KIFS_ERR_BAD_ARG;
     if (!c->have_options) return KIFS_ERR_UNCONFIGURED;
     if (n == 0) return KIFS_OK;
@@ -898,7 +898,7 @@ static int eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, flo
         if (nrm_out && hipMalloc(reinterpret_cast<void**>(&d_nrm), 3 * nb) != hipSuccess) break;
         if (hipMemcpyAsync(d_pts, pts, 3 * nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) break;
         if (kifs::launch_eval_points(P, c->options.fractal_group_id, c->options.primitive_id,
-                                     d_pts, n, d_sdf, d_nrm, paired, c->stream) != hipSuccess) break;
+                                     d_pts, n, d_sdf, d_nrm, c->stream) != hipSuccess) break;
         if (sdf_out && hipMemcpyAsync(sdf_out, d_sdf, nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) break;
         if (nrm_out && hipMemcpyAsync(nrm_out, d_nrm, 3 * nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) break;
         if (hipStreamSynchronize(c->stream) != hipSuccess) break;
@@ -908,18 +908,6 @@ static int eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, flo
     if (d_sdf) (void)hipFree(d_sdf);
     if (d_nrm) (void)hipFree(d_nrm);
     return rc;
-}
-
-int kifs_eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float* nrm_out) {
-    return eval_points(c, pts, n, sdf_out, nrm_out, 0);
-}
-
-int kifs_debug_eval_sierpinski_pairs(kifs_ctx* c, const float* pts, int n, float* sdf_out, int mode) {
-    if (!c || !sdf_out || (mode != 1 && mode != 2)) return KIFS_ERR_BAD_ARG;
-    if (!c->have_options || c->options.fractal_group_id != uint32_t(kifs::GROUP_KIFS) ||
-        c->options.primitive_id != uint32_t(kifs::PRIM_SIERPINSKI))
-        return KIFS_ERR_BAD_ARG;
-    return eval_points(c, pts, n, sdf_out, nullptr, mode);
 }
 
 int kifs_eval_math(kifs_ctx* c, int fn, const float* in, float param, float* out, int n) {

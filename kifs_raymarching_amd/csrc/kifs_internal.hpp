@@ -12,9 +12,8 @@ hipError_t launch_render(const BatchParams& B, uint32_t group, uint32_t primitiv
 // Device-side counting sort: order[] = tile ids (x | y << 16) by descending cost[]; clears cost[].
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_count,
                              uint32_t tiles_x, hipStream_t stream);
-// paired != 0 (Sierpinski only): point i is evaluated as one of the two rays of a lane (with i ^ 1)
 hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,
-                              const float* pts, int n, float* sdf, float* nrm, int paired,
+                              const float* pts, int n, float* sdf, float* nrm,
                               hipStream_t stream);
 hipError_t launch_eval_math(int fn, const float* in, float param, const float* srgb_table,
                             float* out, int n, hipStream_t stream);

@@ -582,21 +582,8 @@ hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_coun
 // ---- point evaluation (parity tests) --------------------------------------------------
 template <int GROUP, int PRIM>
 __global__ void eval_points_kernel(const FrameParams P, const float* __restrict__ pts, int n,
-                                   float* __restrict__ sdf, float* __restrict__ nrm, int paired) {
+                                   float* __restrict__ sdf, float* __restrict__ nrm) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if constexpr (GROUP == GROUP_KIFS && PRIM == PRIM_SIERPINSKI) {
-        if (paired) {  // the two-rays-per-lane fold: point i shares a lane with point i ^ 1
-            const int ia = min(i & ~1, n - 1), ib = min(i | 1, n - 1);
-            const V3 pa{pts[3 * ia], pts[3 * ia + 1], pts[3 * ia + 2]};
-            const V3 pb{pts[3 * ib], pts[3 * ib + 1], pts[3 * ib + 2]};
-            // paired == 2: every third pair marches with its B ray dead (its estimate is unspecified)
-            const bool b_live = !(paired == 2 && ((i >> 1) % 3) == 0);
-            float da, db;
-            sierpinski_sdf2(P, pa, pb, __builtin_amdgcn_ballot_w64(true), __builtin_amdgcn_ballot_w64(b_live), da, db);
-            if (i < n && sdf) sdf[i] = (i & 1) ? db : da;
-            return;
-        }
-    }
     if (i >= n) return;
     V3 p{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     if (sdf) sdf[i] = scene_sdf<GROUP, PRIM>(P, p);
@@ -608,28 +595,28 @@ __global__ void eval_points_kernel(const FrameParams P, const float* __restrict_
 
 template <int GROUP, int PRIM>
 static hipError_t launch_eval_variant(const FrameParams& P, const float* pts, int n, float* sdf,
-                                      float* nrm, int paired, hipStream_t stream) {
+                                      float* nrm, hipStream_t stream) {
     hipLaunchKernelGGL((eval_points_kernel<GROUP, PRIM>), dim3((n + 255) / 256), dim3(256), 0,
-                       stream, P, pts, n, sdf, nrm, paired);
+                       stream, P, pts, n, sdf, nrm);
     return hipGetLastError();
 }
 
 hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,
-                              const float* pts, int n, float* sdf, float* nrm, int paired,
+                              const float* pts, int n, float* sdf, float* nrm,
                               hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     switch (group) {
-    case GROUP_JULIA: return launch_eval_variant<GROUP_JULIA, 0>(P, pts, n, sdf, nrm, paired, stream);
-    case GROUP_GENJULIA: return launch_eval_variant<GROUP_GENJULIA, 0>(P, pts, n, sdf, nrm, paired, stream);
+    case GROUP_JULIA: return launch_eval_variant<GROUP_JULIA, 0>(P, pts, n, sdf, nrm, stream);
+    case GROUP_GENJULIA: return launch_eval_variant<GROUP_GENJULIA, 0>(P, pts, n, sdf, nrm, stream);
     case GROUP_KIFS:
         switch (primitive) {
-        case PRIM_SPHERE: return launch_eval_variant<GROUP_KIFS, PRIM_SPHERE>(P, pts, n, sdf, nrm, paired, stream);
-        case PRIM_CYLINDER: return launch_eval_variant<GROUP_KIFS, PRIM_CYLINDER>(P, pts, n, sdf, nrm, paired, stream);
-        case PRIM_BOX: return launch_eval_variant<GROUP_KIFS, PRIM_BOX>(P, pts, n, sdf, nrm, paired, stream);
-        case PRIM_TORUS: return launch_eval_variant<GROUP_KIFS, PRIM_TORUS>(P, pts, n, sdf, nrm, paired, stream);
-        case PRIM_SIERPINSKI: return launch_eval_variant<GROUP_KIFS, PRIM_SIERPINSKI>(P, pts, n, sdf, nrm, paired, stream);
-        case PRIM_BUNNY: return launch_eval_variant<GROUP_KIFS, PRIM_BUNNY>(P, pts, n, sdf, nrm, paired, stream);
-        default: return launch_eval_variant<GROUP_KIFS, PRIM_OTHER>(P, pts, n, sdf, nrm, paired, stream);
+        case PRIM_SPHERE: return launch_eval_variant<GROUP_KIFS, PRIM_SPHERE>(P, pts, n, sdf, nrm, stream);
+        case PRIM_CYLINDER: return launch_eval_variant<GROUP_KIFS, PRIM_CYLINDER>(P, pts, n, sdf, nrm, stream);
+        case PRIM_BOX: return launch_eval_variant<GROUP_KIFS, PRIM_BOX>(P, pts, n, sdf, nrm, stream);
+        case PRIM_TORUS: return launch_eval_variant<GROUP_KIFS, PRIM_TORUS>(P, pts, n, sdf, nrm, stream);
+        case PRIM_SIERPINSKI: return launch_eval_variant<GROUP_KIFS, PRIM_SIERPINSKI>(P, pts, n, sdf, nrm, stream);
+        case PRIM_BUNNY: return launch_eval_variant<GROUP_KIFS, PRIM_BUNNY>(P, pts, n, sdf, nrm, stream);
+        default: return launch_eval_variant<GROUP_KIFS, PRIM_OTHER>(P, pts, n, sdf, nrm, stream);
         }
     default: return hipErrorInvalidValue;
     }

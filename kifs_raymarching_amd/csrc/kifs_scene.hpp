@@ -373,121 +373,6 @@ KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p, unsigned long long lan
     return (sqrt_(n2) - 2.0f) / scale;
 }
 
-// ---- the fold loop for TWO rays per lane ---------------------------------------------------
-// On the throughput path a lane marches two rays, A in the low and B in the high half of register
-// pairs, and the fold -- add, mul, fma -- runs on v_pk_*_f32: 53 instructions per fold for the two
-// rays where sierpinski_folds needs 41 for one.  What the packed form cannot do is freeze one
-// ray with EXEC.  Instead a ray that has left the loop (n2 >= stop) keeps evolving in its half,
-// unread: its n2 and scale of the last fold it was entitled to are latched (v_cndmask under the
-// ray's own live mask).  The range keys are taken over both halves; a dead ray's garbage (it
-// doubles towards infinity) can at worst send the wave to the exact path once too often.
-// Operation for operation the arithmetic of a live ray is that of KIFS_FOLD_STEP.
-//   v[40:41] X  v[42:43] Y  v[44:45] Z  v[46:47] n2  v[48:49] scale   (.lo = ray A, .hi = ray B)
-//   v[50:51] latched n2   v[52:53] latched scale   v[54:55] q / m   v[56:57] residual
-//   v[58:63] numerators   v64 / v65 smallest key of A / B   v66-v68 key scratch
-//   s[76:77] = [I, I]  s[78:79] = [-c, -c] (c = sqrt 2 = 2/sqrt 2)  s[80:81] / s[82:83] live A / B
-#define KIFS_MIRROR2(num, a, b)                                                               \
-    "v_pk_add_f32 " num ", " a ", " b "\n"                                                    \
-    "v_pk_mul_f32 v[54:55], " num ", s[76:77]\n"             /* q0 = x * I */                 \
-    "v_pk_fma_f32 v[56:57], v[54:55], s[78:79], " num "\n"   /* e1 = fma(-c, q0, x) */        \
-    "v_pk_fma_f32 v[54:55], v[56:57], s[76:77], v[54:55]\n"  /* q1 = fma(e1, I, q0) */        \
-    "v_pk_fma_f32 v[56:57], v[54:55], s[78:79], " num "\n"   /* e2 = fma(-c, q1, x) */        \
-    "v_pk_fma_f32 v[54:55], v[56:57], s[76:77], v[54:55]\n"  /* q2 = fma(e2, I, q1) */        \
-    "v_min_f32_e32 v54, 0, v54\n"                                                             \
-    "v_min_f32_e32 v55, 0, v55\n"                                                             \
-    "v_pk_fma_f32 " a ", v[54:55], s[78:79], " a "\n"        /* p -= m * (2/sqrt 2) */        \
-    "v_pk_fma_f32 " b ", v[54:55], s[78:79], " b "\n"
-
-#define KIFS_FOLD_STEP2                                                                       \
-    KIFS_MIRROR2("v[58:59]", "v[40:41]", "v[42:43]")                                          \
-    KIFS_MIRROR2("v[60:61]", "v[42:43]", "v[44:45]")                                          \
-    KIFS_MIRROR2("v[62:63]", "v[40:41]", "v[44:45]")                                          \
-    "v_pk_fma_f32 v[40:41], v[40:41], 2.0, -1.0 op_sel_hi:[1,0,0]\n"   /* p = 2 p - 1 */      \
-    "v_pk_fma_f32 v[42:43], v[42:43], 2.0, -1.0 op_sel_hi:[1,0,0]\n"                          \
-    "v_pk_fma_f32 v[44:45], v[44:45], 2.0, -1.0 op_sel_hi:[1,0,0]\n"                          \
-    "v_pk_add_f32 v[48:49], v[48:49], v[48:49]\n"                      /* scale *= 2 */       \
-    "v_pk_mul_f32 v[46:47], v[40:41], v[40:41]\n"                      /* n2 = dot(p, p) */   \
-    "v_pk_fma_f32 v[46:47], v[42:43], v[42:43], v[46:47]\n"                                   \
-    "v_pk_fma_f32 v[46:47], v[44:45], v[44:45], v[46:47]\n"                                   \
-    "v_lshl_add_u32 v66, v58, 1, -1\n"                                  /* range keys, ray A */\
-    "v_lshl_add_u32 v67, v60, 1, -1\n"                                                        \
-    "v_lshl_add_u32 v68, v62, 1, -1\n"                                                        \
-    "v_min3_u32 v64, v66, v67, v64\n"                                                         \
-    "v_min_u32_e32 v64, v68, v64\n"                                                           \
-    "v_lshl_add_u32 v66, v59, 1, -1\n"                                  /* ray B */           \
-    "v_lshl_add_u32 v67, v61, 1, -1\n"                                                        \
-    "v_lshl_add_u32 v68, v63, 1, -1\n"                                                        \
-    "v_min3_u32 v65, v66, v67, v65\n"                                                         \
-    "v_min_u32_e32 v65, v68, v65\n"                                                           \
-    "v_cndmask_b32_e64 v50, v50, v46, s[80:81]\n"   /* latch what a ray live in this fold got */ \
-    "v_cndmask_b32_e64 v52, v52, v48, s[80:81]\n"                                             \
-    "v_cndmask_b32_e64 v51, v51, v47, s[82:83]\n"                                             \
-    "v_cndmask_b32_e64 v53, v53, v49, s[82:83]\n"                                             \
-    "v_cmp_gt_f32_e64 s[86:87], %[stop], v46\n"     /* still below stop? */                   \
-    "v_cmp_gt_f32_e64 s[88:89], %[stop], v47\n"                                               \
-    "s_and_b64 s[80:81], s[80:81], s[86:87]\n"                                                \
-    "s_and_b64 s[82:83], s[82:83], s[88:89]\n"                                                \
-    "s_or_b64 exec, s[80:81], s[82:83]\n"
-
-// Folds of two rays per lane.  In: positions, squared norms, which lanes' A / B rays count.  Out:
-// n2 and scale of each ray as its own loop left them.  Returns false when the wave must recompute
-// exactly (a numerator below 2^-102, see sierpinski_folds).
-KIFS_DEV bool sierpinski_folds2(const FrameParams& P, V3 pa, V3 pb, float& n2a, float& n2b, float& sca,
-                                float& scb, unsigned long long lanes_a, unsigned long long lanes_b) {
-    F2 x{pa.x, pb.x}, y{pa.y, pb.y}, z{pa.z, pb.z}, n2{n2a, n2b}, sc{1.0f, 1.0f};
-    F2 n2f = n2, scf = sc, q, e, x1, x2, x3;
-    unsigned key_a = 0xffffffffu, key_b = 0xffffffffu, k1, k2, k3;
-    const float inv = 1.0f / sqrt_(2.0f), negc = -sqrt_(2.0f);
-    const F2 kI{inv, inv}, kC{negc, negc};
-    int n = P.fold_iters;
-    unsigned long long saved_exec;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n"
-        "s_cmp_lt_i32 %[n], 1\n"
-        "s_cbranch_scc1 1f\n"
-        "v_cmp_gt_f32_e64 s[86:87], %[stop], v46\n"
-        "v_cmp_gt_f32_e64 s[88:89], %[stop], v47\n"
-        "s_and_b64 s[80:81], s[86:87], %[la]\n"
-        "s_and_b64 s[82:83], s[88:89], %[lb]\n"
-        "s_or_b64 s[86:87], s[80:81], s[82:83]\n"
-        "s_and_b64 exec, exec, s[86:87]\n"
-        "s_cbranch_execz 1f\n"
-        ".p2align 6\n"
-        "0:\n"
-        KIFS_FOLD_STEP2
-        "s_sub_u32 %[n], %[n], 1\n"
-        "s_cmp_eq_u32 %[n], 0\n"
-        "s_cbranch_scc1 1f\n"
-        "s_cbranch_execnz 0b\n"
-        "1:\n"
-        "s_mov_b64 exec, %[save]\n"
-        : "+{v[40:41]}"(x), "+{v[42:43]}"(y), "+{v[44:45]}"(z), "+{v[46:47]}"(n2), "+{v[48:49]}"(sc),
-          "+{v[50:51]}"(n2f), "+{v[52:53]}"(scf), "=&{v[54:55]}"(q), "=&{v[56:57]}"(e),
-          "=&{v[58:59]}"(x1), "=&{v[60:61]}"(x2), "=&{v[62:63]}"(x3), "+{v64}"(key_a), "+{v65}"(key_b),
-          "=&{v66}"(k1), "=&{v67}"(k2), "=&{v68}"(k3), [save] "=&s"(saved_exec), [n] "+s"(n)
-        : [stop] "s"(P.fold_n2_stop), "{s[76:77]}"(kI), "{s[78:79]}"(kC), [la] "s"(lanes_a), [lb] "s"(lanes_b)
-        : "vcc", "scc", "s80", "s81", "s82", "s83", "s86", "s87", "s88", "s89");
-    n2a = n2f.x;
-    n2b = n2f.y;
-    sca = scf.x;
-    scb = scf.y;
-    const unsigned key = key_a < key_b ? key_a : key_b;
-    return __builtin_amdgcn_ballot_w64(key < ((25u << 24) - 1u)) == 0ull;
-}
-
-// Estimates of two rays per lane (`lanes_a` / `lanes_b`: whose A / B estimate the caller uses).
-KIFS_DEV void sierpinski_sdf2(const FrameParams& P, V3 pa, V3 pb, unsigned long long lanes_a,
-                              unsigned long long lanes_b, float& da, float& db) {
-    float n2a = dot(pa, pa), n2b = dot(pb, pb), sca = 1.0f, scb = 1.0f;
-    if (__builtin_expect(!sierpinski_folds2(P, pa, pb, n2a, n2b, sca, scb, lanes_a, lanes_b), 0)) {
-        da = sierpinski_sdf(P, pa, lanes_a);  // (tries the one-ray loop, then true divisions)
-        db = sierpinski_sdf(P, pb, lanes_b);
-        return;
-    }
-    da = (sqrt_(n2a) - 2.0f) / sca;
-    db = (sqrt_(n2b) - 2.0f) / scb;
-}
-
 KIFS_DEV V4 mat4_vec(const float* m, V4 v) {  // column-major 4x4 times vector
     V4 r;
     r.x = fmaf_(m[12], v.w, fmaf_(m[8], v.z, fmaf_(m[4], v.y, m[0] * v.x)));

@@ -345,15 +345,6 @@ class GraphicState:
         check(lib.kifs_eval_points(self._ctx, fp(pts), n, fp(sdf), fp(nrm)), "eval_points")
         return sdf, nrm
 
-    def debug_eval_sierpinski_pairs(self, points, mode: int = 1):
-        """Sierpinski estimates through the two-rays-per-lane fold (point i with point i ^ 1)."""
-        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
-        sdf = np.empty(pts.shape[0], dtype=np.float32)
-        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-        check(lib.kifs_debug_eval_sierpinski_pairs(self._ctx, fp(pts), pts.shape[0], fp(sdf), int(mode)),
-              "debug_eval_sierpinski_pairs")
-        return sdf
-
     def debug_counters(self, enable: bool = True):
         """Switch per-wave diagnostics on/off (and reset them); returns the sums of the records
         written since the last call (see kifs_debug_wave_records)."""

@@ -131,32 +131,3 @@ def test_encoders_bit_exact(gs, oracle):
         got = gs.eval_math(fn, xs)
         want = np.array([enc(float(x), mode) for x in xs], dtype=F)
         assert (got == want).all(), mode
-
-
-@pytest.mark.parametrize("name,gui,iters", [c for c in CASES if c[0].startswith("sierpinski")],
-                         ids=[c[0] for c in CASES if c[0].startswith("sierpinski")])
-@pytest.mark.parametrize("mode", [1, 2])
-def test_two_rays_per_lane_fold_bit_exact(name, gui, iters, mode, gs, kifs, oracle):
-    """The throughput path folds two rays per lane on packed f32 (sierpinski_folds2).  Every point
-    is evaluated once as ray A or B of a lane, next to a neighbour that may leave the fold loop
-    earlier or later, be dead from the start (mode 2), or carry zeros, denormals, infinities and
-    NaN: its estimate must not depend on the company."""
-    g = kifs.GuiData(**gui)
-    gs.update_options(g)
-    gs.set_iters(*iters)
-    n = 4096
-    pts = points(n, seed=7 + hash(name) % 1000, radius=2.5)
-    rng = np.random.default_rng(5)
-    pts[20:1000] *= rng.choice([1.0, 50.0, 1e4, 1e-3], size=(980, 1)).astype(F)  # mixed fold counts per pair
-    got = gs.debug_eval_sierpinski_pairs(pts, mode)
-    o = oracle.from_bytes(oracle.Options, kifs.uniform_bytes(g.into_buffer_data()))
-    it = oracle.iters(*iters)
-    L = oracle.lib()
-    want = np.array([L.kor_scene_sdf(C.byref(o), C.byref(it), (C.c_float * 3)(*pts[i])) for i in range(n)],
-                    dtype=F)
-    check = np.ones(n, dtype=bool)
-    if mode == 2:  # the B ray (odd index) of every third pair was dead: unspecified
-        idx = np.arange(n)
-        check &= ~(((idx >> 1) % 3 == 0) & (idx % 2 == 1))
-    bad = ~same_bits(got, want) & check
-    assert not bad.any(), (name, mode, int(bad.sum()), np.nonzero(bad)[0][:5], pts[bad][:3], got[bad][:3], want[bad][:3])
