@@ -324,8 +324,8 @@ TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
 // with real work are those the projected bounding sphere covers.  If those are few enough to be
 // spread over the 256 CUs in a couple of rounds, capping residency lets every long wave run
 // near its lone-wave speed (1080p, camera at distance 5: 207 -> 172 us at one workgroup per
-// CU); if they are many (4096^2, or a camera close to the fractal) the frame is bound by their
-// number of slots for long-marching waves and full residency wins (4096^2: 0.70 ms vs 1.95 ms capped).
+// CU); if they are many (4096^2, or a camera close to the fractal) the frame needs every slot for
+// its long-marching waves and full residency wins (4096^2: 0.70 ms vs 1.95 ms capped).
 int residency_for(const kifs::FrameParams& P, uint32_t group, int frame_height, uint32_t tile_count) {
     if (group != kifs::GROUP_JULIA || P.cull_n2 <= 0.0f || P.is_heatmap) return 0;
     const double R2 = double(P.cull_n2) / 1.1;  // (2 + epsilon)^2
