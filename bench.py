@@ -3,29 +3,39 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A "step" is one launch of the render path per rank over its batch of synthetic input:
-`--frames-per-launch` frames of the workload's sequence (default 8, one camera and one
-destination each; 1 = the lone-frame latency path), rendered by one kifs_render_batch_async
-call.  At N > 1 (one process per GPU, launched by torch.distributed.run) the default is
-frame-parallel: in step k rank r renders frames (k N + r) B .. + B - 1 of the sequence.
-Frames are independent units, so there is no exchange step: each frame stays in the HBM of
-the GPU that rendered it (weak scaling: per-GPU work is fixed, value = N x B x pixels per
-step / time); `--deliver root` ships the finished frames to rank 0 by grouped RCCL
-point-to-point transfers over xGMI instead.  `--shard bands` splits every frame into row
-bands gathered into rank 0's frame (strong scaling of one frame: the low-latency mode; it
-cannot raise throughput much because every band still contains the frame's longest rays --
-DESIGN.md section 6).  The default workload is BASELINE.json's metric configuration:
-1920x1080 quaternion-Julia, 256 march steps, 12 SDF iterations.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the render path over one batch of synthetic input: the next
+`--frames-per-launch` (default 8) frames of the workload's ORBIT -- one camera pose and one
+destination per frame, packed by the host camera model exactly as the reference does per frame
+(render.rs:320-345) -- rendered by one kifs_render_batch_async launch.  The default workload is
+BASELINE.json's metric configuration: 1920x1080 quaternion-Julia, 256 march steps, 12 SDF
+iterations.  Rank 0 prints ONE JSON line; besides the headline it carries, measured in the same
+process after the timed region, `secondary.lone_frame` (one frame per launch: the latency path)
+and `secondary.fixed_camera` (the same view in every slot of the batch: the most favourable case
+for the tile-order feedback).
 
-There are no HBM-resident inputs beyond the 156 uniform bytes; the output frame lives in
-HBM (torch tensor) and is written by the kernel.  `roofline` prices the dominant kernel
-against the HBM-write roofline the north star mandates (4 algorithmic bytes per pixel);
-`cpu_baseline` times the CPU oracle (the stand-in for the reference's wgpu path, which
-cannot run here) on the host cores -- a reported baseline, not the target.
+N > 1 (one process per GPU; `python bench.py --gpus N` launches the N ranks itself, or it runs
+under torch.distributed.run): the north star's path.  Every frame is split into ROW SHARDS --
+its 8-row stripes dealt to the ranks in turn, so that every rank gets its share of the expensive
+middle rows -- each rank renders its stripes of all the step's frames with one launch, sends them
+to rank 0 in ONE message (grouped RCCL point-to-point: every sender -> root pair rides its own
+xGMI link), and rank 0 moves the received stripes to their rows of the final frames.  Weak
+scaling by default: a step has N x frames-per-launch frames, so every GPU keeps rendering
+frames-per-launch frames' worth of pixels per step (`--scaling strong` fixes the step at
+frames-per-launch frames instead).  `--shard bands` uses contiguous runs of stripes,
+`--shard frames` whole frames per rank (no exchange unless `--deliver root`); the latter is also
+measured after the timed region and reported as `secondary.frame_parallel`.
+
+There are no HBM-resident inputs beyond the 156 uniform bytes; the output frames live in HBM
+(torch tensors) and are written by the kernel.  `roofline` prices the dominant kernel against
+the HBM-write roofline the north star mandates (4 algorithmic bytes per pixel); `cpu_baseline`
+times the CPU oracle (the stand-in for the reference's wgpu path, which cannot run here) on the
+host cores -- a reported baseline, not the target.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -35,6 +45,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_F32_PEAK_TFLOPS = 157.3  # MI355X vector f32 (same guide); the path has no MFMA work
 METRIC = "Mpixels/s at 1920x1080, 256 march steps, 12 SDF iters; %HBM-peak"
 
 
@@ -47,39 +58,91 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall-clock budget of the cpu_baseline sample (0 disables it)")
     ap.add_argument("--encode", type=int, default=1, help="1 = sRGB target (reference default), 0 = UNORM")
-    ap.add_argument("--orbit", action="store_true",
-                    help="move the camera every frame (phi = 2*pi*frame/frames of the workload, "
-                         "host camera model + 64-byte uniform update per step) instead of re-rendering one view")
-    ap.add_argument("--shard", default="frames", choices=["frames", "bands"],
-                    help="N > 1: whole frames per rank (throughput, default) or row bands of each frame (latency)")
+    ap.add_argument("--camera", default="orbit", choices=["orbit", "fixed"],
+                    help="orbit (default): a distinct pose per frame, phi = 2*pi*frame/120 (host camera model + "
+                         "64-byte uniform per frame); fixed: every frame is the workload's view")
+    ap.add_argument("--orbit", action="store_true", help="same as --camera orbit (kept for older scripts)")
+    ap.add_argument("--frames-per-launch", type=int, default=8,
+                    help="frames of the sequence per launch (1..32); 1 = the lone-frame latency path")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="N = 1 only: launches kept in flight on separate contexts and streams")
+    ap.add_argument("--shard", default="stripes", choices=["stripes", "bands", "frames"],
+                    help="N > 1: interleaved 8-row stripes of every frame gathered to rank 0 (default), "
+                         "contiguous row bands gathered to rank 0, or whole frames per rank")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1, row shards: frames per step = N x frames-per-launch (weak) or frames-per-launch")
+    ap.add_argument("--root-weight", type=int, default=1,
+                    help="N > 1, stripes: rank 0 renders this many stripes for every one of a peer "
+                         "(the root's xGMI ingest is the bottleneck of a gather)")
+    ap.add_argument("--deliver", default="none", choices=["none", "root"],
+                    help="N > 1, --shard frames: leave frames where they were rendered, or send them to rank 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo is only for rehearsing N > 1 on one GPU")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--frames-per-launch", type=int, default=8,
-                    help="frames of the sequence rendered by one launch (kifs_render_batch_async, 1..8); "
-                         "1 = one frame per launch, the lone-frame latency path")
-    ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="launches each rank keeps in flight on separate contexts and streams")
-    ap.add_argument("--deliver", default="none", choices=["none", "root"],
-                    help="N > 1, --shard frames: leave every frame in the HBM of the GPU that rendered it "
-                         "(frames are independent units: no exchange step), or ship them to rank 0 by "
-                         "grouped RCCL p2p")
     ap.add_argument("--check", action="store_true",
-                    help="after the timed region, compare rank 0's gathered frame with a single-GPU render")
+                    help="after the timed region, compare rank 0's gathered frames with single-GPU renders")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
     return ap.parse_args()
+
+
+# ---- N > 1 without a launcher: start the ranks ------------------------------------------------
+def self_launch(args):
+    """Starts one fresh child process per GPU and relays rank 0's JSON line.  Runs BEFORE anything
+    in this process touches the GPU (no torch import, no HIP call): a process that has initialised
+    the GPU must never be replaced or forked into ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else sys.stderr))
+        # a rank that dies leaves the others waiting in a collective: stop them (exactly the
+        # children started above) instead of waiting for a communicator time-out
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.returncode not in (None, 0) for p in procs):
+                failed = True
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                t_end = time.time() + 10
+                for p in procs:
+                    try:
+                        p.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            time.sleep(0.05)
+        failed = failed or any(p.returncode != 0 for p in procs)
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    if failed:
+        sys.exit(f"bench.py: a rank failed (exit codes {[p.returncode for p in procs]})")
+
+
+# ---- CPU-side figures ----------------------------------------------------------------------------
+def _oracle_uniforms(w, camera=None):
+    import oracle as O
+    import kifs_raymarching_amd as K
+
+    ub = K.uniform_bytes
+    return (O.from_bytes(O.Screen, ub(w.screen.into_buffer_data())),
+            O.from_bytes(O.Camera, ub((camera or w.camera).into_buffer_data())),
+            O.from_bytes(O.Options, ub(w.gui.into_buffer_data())), O.iters(*w.iters))
 
 
 def cpu_baseline(w, seconds):
     """Times the CPU oracle on whole frames of the same workload for ~`seconds`."""
     import oracle as O
-    import kifs_raymarching_amd as K
 
-    ub = K.uniform_bytes
-    s = O.from_bytes(O.Screen, ub(w.screen.into_buffer_data()))
-    c = O.from_bytes(O.Camera, ub(w.camera.into_buffer_data()))
-    o = O.from_bytes(O.Options, ub(w.gui.into_buffer_data()))
-    it = O.iters(*w.iters)
+    s, c, o, it = _oracle_uniforms(w)
     cores = len(os.sched_getaffinity(0))
     # bound the sample: time a slice first, then whole frames while the budget lasts
     rows = max(8, w.screen.height // 16)
@@ -108,9 +171,6 @@ def cpu_baseline(w, seconds):
             "sample": sample + f", C oracle ({O.lib()._variant}), {cores} threads"}
 
 
-VALU_F32_PEAK_TFLOPS = 157.3  # MI355X vector f32 (MI355X_MICROARCH.md); the path has no MFMA work
-
-
 def work_count(w, kernel_s):
     """Secondary figure of SURVEY 8(d): algorithmic flops of one frame, counted by the
     instrumented CPU oracle (march steps, Julia iterations / Sierpinski folds, hits), against
@@ -119,13 +179,8 @@ def work_count(w, kernel_s):
     40 * normal_iters (Julia Jacobian) -- the six extra SDF calls of a KIFS normal are already
     in the step and fold counts."""
     import oracle as O
-    import kifs_raymarching_amd as K
 
-    ub = K.uniform_bytes
-    s = O.from_bytes(O.Screen, ub(w.screen.into_buffer_data()))
-    c = O.from_bytes(O.Camera, ub(w.camera.into_buffer_data()))
-    o = O.from_bytes(O.Options, ub(w.gui.into_buffer_data()))
-    it = O.iters(*w.iters)
+    s, c, o, it = _oracle_uniforms(w)
     W, H = w.screen.width, w.screen.height
     stride = max(1, (W * H + (1 << 22) - 1) >> 22)  # count every stride-th row of big frames
     steps = inner = hits = calls = rows = 0
@@ -148,39 +203,40 @@ def work_count(w, kernel_s):
             "march_steps_per_pixel": round(steps * scale / (W * H), 2),
             "inner_iterations_per_step": round(inner / max(calls, 1), 3),
             "hit_fraction": round(hits * scale / (W * H), 5),
-            "sample": "whole frame" if stride == 1 else f"every {stride}th row, scaled"}
+            "sample": ("whole frame" if stride == 1 else f"every {stride}th row, scaled") + ", the workload's own view"}
 
 
 def pmc_traffic(workload_key, frames_per_launch=1):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass, if one exists (keyed by
-    workload, and workload@B for launches of B frames)."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (counters cannot be read from
+    inside the process), keyed by workload and workload@B; (bytes or None, source)."""
     p = ROOT / "profiles" / "pmc_traffic.json"
     if frames_per_launch > 1:
         workload_key = f"{workload_key}@{frames_per_launch}"
     try:
         rec = json.loads(p.read_text()).get(workload_key)
-        return rec["hbm_bytes_per_launch"] if rec else None
+        return (rec["hbm_bytes_per_launch"] if rec else None), "profiles/pmc_traffic.json"
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def main():
     args = parse()
+    if args.orbit:
+        args.camera = "orbit"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+
     import torch
     import torch.distributed as dist
 
     import kifs_raymarching_amd as K
-    from kifs_raymarching_amd.bands import BandFrame, FrameStream
+    from kifs_raymarching_amd.bands import FrameStream, ShardFrames
     from kifs_raymarching_amd.configs import HEADLINE, WORKLOADS, orbit_camera
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run "
-                     "(one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the render path has no CPU fallback")
     if args.share_device:
@@ -196,10 +252,11 @@ def main():
     key = args.workload or HEADLINE
     w = WORKLOADS[key]
     W, H = w.screen.width, w.screen.height
-    # F frames in flight: F contexts, each with its own stream, tile tables and output buffer;
-    # step k uses context k % F.  Kernel launches, events and the RCCL gather's stream
-    # dependencies of a step all sit on that context's dedicated non-default stream.
-    F = max(1, args.frames_in_flight)
+    orbit_len = max(w.frames, 120)
+    # F launches in flight (N = 1): F contexts, each with its own stream, tile tables and output
+    # buffers; step k uses context k % F.  Launches, events and the RCCL stream dependencies of a
+    # step all sit on that context's dedicated non-default stream.
+    F = max(1, args.frames_in_flight) if world == 1 else 1
     gss, streams = [], []
     for _ in range(F):
         g = K.GraphicState(local_rank, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
@@ -209,117 +266,205 @@ def main():
         g.set_frames_in_flight(F)
         gss.append(g)
         streams.append(torch.cuda.Stream(device=device))
-    gs, stream = gss[0], streams[0]
-    torch.cuda.set_stream(stream)
+    gs = gss[0]
+    torch.cuda.set_stream(streams[0])
     buffers = F if F >= 2 else 2  # buffer slot k % buffers always belongs to stream k % F
-    bands_mode = world > 1 and args.shard == "bands"
-    frames_mode = world > 1 and not bands_mode
-    B = 1 if bands_mode else max(1, min(args.frames_per_launch, K.MAX_BATCH))
-    cur = [0]  # index of the context / stream of the step being enqueued
-    if not bands_mode:
-        # a step's B frames are stacked in one (B*H, W, 4) buffer
-        bf = FrameStream(W, B * H, rank, world, device, buffers=buffers,
-                         deliver=(args.deliver == "root"))
-        rows0 = H
+    B = max(1, min(args.frames_per_launch, K.MAX_BATCH))
 
-        def render_band(out, step_index):  # without --orbit every frame is the same view
-            g, st = gss[cur[0]], streams[cur[0]]
-            first = step_index * B
-            cams = [orbit_camera(w, (first + i) % max(w.frames, 120)) if args.orbit else w.camera
-                    for i in range(B)]
-            if B == 1:
-                if args.orbit:
-                    g.set_camera(cams[0])
-                g.render_async(out, stream=st, y0=0, y1=H, encode=args.encode)
-            else:
-                g.render_batch_async([out[i * H:(i + 1) * H] for i in range(B)], cams, stream=st,
-                                     y0=0, y1=H, encode=args.encode)
-    else:
-        bf = BandFrame(W, H, rank, world, device, buffers=buffers)
-        rows0 = bf.y1 - bf.y0
-
-        orbit_frame = [0]
-
-        def render_band(out, y0, y1):
-            if args.orbit:
-                gss[cur[0]].set_camera(orbit_camera(w, orbit_frame[0] % max(w.frames, 120)))
-                orbit_frame[0] += 1
-            gss[cur[0]].render_async(out, stream=streams[cur[0]], y0=y0, y1=y1, encode=args.encode)
-
-    def step(k):
-        cur[0] = k % F
-        with torch.cuda.stream(streams[cur[0]]):
-            bf.step(k, render_band)
+    def cameras(first, n, mode):
+        return [orbit_camera(w, (first + i) % orbit_len) if mode == "orbit" else w.camera for i in range(n)]
 
     def barrier():
         if world > 1:
-            if args.backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
+
+    def run(pipeline, step, steps, warmup):
+        """warmup + timed loop of `step(k)`; returns wall seconds and the per-launch kernel times
+        (HIP event pairs recorded by the library on the launch stream around the render kernel)."""
+        for k in range(warmup):
+            step(k)
+        pipeline.wait_all()
+        torch.cuda.synchronize()
+        for g in gss:
+            g.set_profiling(4)  # every 4th launch: an event pair costs a few microseconds
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k)
+        pipeline.wait_all()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        reads = [g.profile_read() for g in gss]
+        for g in gss:
+            g.set_profiling(0)
+        n = sum(r[0] for r in reads)
+        return {"elapsed": elapsed, "launches_timed": n,
+                "kernel_ms": sum(r[0] * r[1] for r in reads) / max(n, 1),
+                "kernel_ms_min": min((r[2] for r in reads if r[0] > 0), default=0.0),
+                "kernel_ms_max": max((r[3] for r in reads if r[0] > 0), default=0.0),
+                "round_steps": gss[0].debug_last_round_steps()}
+
+    def whole_frames(frames_per_launch, camera_mode, deliver=False):
+        """Every rank renders whole frames: step k, rank r: frames (k N + r) b .. + b - 1 (at N = 1
+        simply the next b frames), stacked in one (b*H, W, 4) buffer."""
+        b = frames_per_launch
+        fs = FrameStream(W, b * H, rank, world, device, buffers=buffers, deliver=deliver)
+
+        cur = [0]
+
+        def render(out, step_index):
+            g, st = gss[cur[0]], streams[cur[0]]
+            cams = cameras(step_index * b, b, camera_mode)
+            if b == 1:
+                g.set_camera(cams[0])  # the reference's per-frame uniform upload (render.rs:320-321)
+                g.render_async(out, stream=st, y0=0, y1=H, encode=args.encode)
             else:
-                dist.barrier()
+                g.render_batch_async([out[i * H:(i + 1) * H] for i in range(b)], cams, stream=st,
+                                     y0=0, y1=H, encode=args.encode)
 
-    for k in range(args.warmup):
-        step(k)
-    bf.wait_all()
-    torch.cuda.synchronize()
+        def step(k):
+            cur[0] = k % F
+            with torch.cuda.stream(streams[cur[0]]):
+                fs.step(k, render)
+        return fs, step
 
-    # HIP events around the render kernel itself (recorded by the library on the launch stream,
-    # one launch in eight): the roofline's "average launch duration"
-    for g in gss:
-        g.set_profiling(8)  # every 8th launch: an event pair costs a few microseconds
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    bf.wait_all()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = elapsed * 1e3  # this rank's wall time between the two synchronisation points
-    # which kernel the launches used: the re-queuing throughput kernel or the one-wave-per-block one
-    bunny = int(w.gui.fractal_group) == 0 and int(w.gui.primitive_shape) == 5
-    kernel_name = ("render_group_kernel" if gss[0].debug_last_round_steps() > 0 else
-                   "render_bunny_quad_kernel" if bunny else "render_kernel")
-    reads = [g.profile_read() for g in gss]
-    timed_launches = sum(r[0] for r in reads)
-    kernel_mean_ms = sum(r[0] * r[1] for r in reads) / max(timed_launches, 1)
-    kernel_min_ms = min((r[2] for r in reads if r[0] > 0), default=0.0)
-    kernel_max_ms = max((r[3] for r in reads if r[0] > 0), default=0.0)
-    for g in gss:
-        g.set_profiling(0)
+    def row_shards(frames_per_step, camera_mode, contiguous):
+        """The north star's path: every rank renders its row shard of the step's frames (launches of
+        at most MAX_BATCH frames) and rank 0 gathers them."""
+        weights = None
+        if not contiguous and args.root_weight != 1:
+            weights = [args.root_weight] + [1] * (world - 1)
+        sf = ShardFrames(W, H, rank, world, device, frames_per_step=frames_per_step, buffers=2,
+                         weights=weights, contiguous=contiguous,
+                         unpack=lambda frames, shards, stripes: gs.unpack_shard_async(
+                             frames, shards, stripes, stream=streams[0]))
 
+        def render(outs, first_frame, stripes, in_place):
+            cams = cameras(first_frame, len(outs), camera_mode)
+            for a in range(0, len(outs), K.MAX_BATCH):
+                gs.render_shard_async(outs[a:a + K.MAX_BATCH], cams[a:a + K.MAX_BATCH], stripes,
+                                      in_place=in_place, stream=streams[0], encode=args.encode)
+
+        def step(k):
+            with torch.cuda.stream(streams[0]):
+                sf.step(k, render)
+        return sf, step
+
+    # ---- the headline sequence
+    sharded = world > 1 and args.shard in ("stripes", "bands")
+    if sharded:
+        frames_per_step = B * world if args.scaling == "weak" else B
+        pipe, step = row_shards(frames_per_step, args.camera, contiguous=(args.shard == "bands"))
+        rows0 = pipe.rows[rank]
+        frames_per_launch = min(frames_per_step, K.MAX_BATCH)
+        launches_per_step = -(-frames_per_step // K.MAX_BATCH)
+    else:
+        pipe, step = whole_frames(B, args.camera, deliver=(args.deliver == "root"))
+        frames_per_step = B * world
+        rows0, frames_per_launch, launches_per_step = H, B, 1
+    m = run(pipe, step, args.steps, args.warmup)
+    elapsed = m["elapsed"]
+
+    check = None
+    if args.check:
+        last = args.warmup + args.steps - 1
+        if rank == 0:
+            ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
+
+            def single(frame_index):
+                gs.set_camera(cameras(frame_index, 1, args.camera)[0])
+                gs.render(out=ref, encode=args.encode)
+                return ref
+            if sharded:
+                got = pipe.frames(last)
+                check = all(bool(torch.equal(got[i], single(last * frames_per_step + i)))
+                            for i in range(frames_per_step))
+            else:  # every frame of the step's batch, from every rank that delivered one
+                delivered = pipe.frames(last)
+                check = all(bool(torch.equal(f[i * H:(i + 1) * H], single((last * world + r) * B + i)))
+                            for r, f in enumerate(delivered) for i in range(B))
+            gs.set_camera(w.camera)
+
+    # ---- secondary measurements, same process, after the timed region
+    secondary = {}
+    alg_frame = 4.0 * W * H  # 4 B written per pixel, 0 read (SURVEY 8d)
+
+    def summarise(mm, frames, steps, note):
+        ms = mm["elapsed"] / steps * 1e3
+        k_ms = mm["kernel_ms"] if mm["launches_timed"] else ms
+        return {"frames_per_launch": frames, "steps": steps, "ms_per_step": round(ms, 5),
+                "mpix_s": round(frames * W * H / (ms * 1e-3) / 1e6, 2), "kernel_ms": round(k_ms, 5),
+                "hbm_frac": round(frames * alg_frame / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "note": note}
+
+    if not args.no_secondary:
+        sec_steps = max(20, min(args.steps, 200))
+        sec_warm = max(6, min(args.warmup, 20))
+        if world == 1:
+            if B != 1:
+                p2, s2 = whole_frames(1, "orbit")
+                secondary["lone_frame"] = summarise(
+                    run(p2, s2, sec_steps, sec_warm), 1, sec_steps,
+                    "one frame per launch, a new orbit pose and a 64-byte camera upload per frame: the latency path")
+            if not (B == 8 and args.camera == "fixed"):
+                p3, s3 = whole_frames(8, "fixed")
+                secondary["fixed_camera"] = summarise(
+                    run(p3, s3, sec_steps, sec_warm), 8, sec_steps,
+                    "8 copies of the workload's view per launch (round 1's headline): the best case of the tile-order feedback")
+        elif args.shard != "frames":
+            p4, s4 = whole_frames(B, args.camera, deliver=False)
+            mm = run(p4, s4, sec_steps, sec_warm)
+            t = torch.tensor([mm["elapsed"]], dtype=torch.float64,
+                             device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mm["elapsed"] = float(t.item())
+            sec = summarise(mm, B, sec_steps, f"frame-parallel: every rank renders whole frames ({B} per launch) and "
+                            "keeps them in its own HBM; no exchange step, so NOT the north star's gathered frame")
+            sec["mpix_s"] = round(sec["mpix_s"] * world, 2)  # whole job: N ranks x B frames per step
+            secondary["frame_parallel"] = sec
+
+    # ---- reduce over ranks
     if world > 1:
         red_dev = device if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tk = torch.tensor([dev_ms], dtype=torch.float64, device=red_dev)
-        gathered = [torch.zeros_like(tk) for _ in range(world)]
-        dist.all_gather(gathered, tk)
-        per_rank_ms = [float(x.item()) / args.steps for x in gathered]
+        mine = torch.tensor([m["kernel_ms"] * launches_per_step, m["elapsed"] / args.steps * 1e3],
+                            dtype=torch.float64, device=red_dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_kernel_ms = [float(x[0].item()) for x in gathered]
+        per_rank_step_ms = [float(x[1].item()) for x in gathered]
     else:
-        per_rank_ms = [dev_ms / args.steps]
-
-    check = None
-    if args.check and rank == 0:
-        last = args.warmup + args.steps - 1
-        ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
-        gs.render(out=ref, encode=args.encode)
-        if not bands_mode:  # every frame of the step's batch, from every rank that delivered one
-            check = all(bool(torch.equal(f[i * H:(i + 1) * H], ref))
-                        for f in bf.frames(last) for i in range(B))
-        else:
-            check = bool(torch.equal(bf.frame(last), ref))
+        per_rank_kernel_ms = [m["kernel_ms"]]
+        per_rank_step_ms = [m["elapsed"] / args.steps * 1e3]
 
     if rank == 0:
-        frames_per_step = (world if frames_mode else 1) * B
         mpix = frames_per_step * W * H * args.steps / elapsed / 1e6
+        bunny = int(w.gui.fractal_group) == 0 and int(w.gui.primitive_shape) == 5
+        kernel_name = ("render_group_kernel" if m["round_steps"] > 0 else
+                       "render_bunny_quad_kernel" if bunny else "render_kernel")
         # average duration of the dominant kernel over the timed region (per-launch event pairs);
-        # dev_ms / steps additionally contains the inter-launch gaps
-        launch_s = (kernel_mean_ms if timed_launches > 0 else dev_ms / args.steps) / 1e3
-        alg_bytes = 4.0 * W * rows0 * B  # 4 B written per pixel, 0 read; B frames per launch
+        # ms_per_step additionally contains the inter-launch gaps and, at N > 1, the exchange
+        launch_s = (m["kernel_ms"] if m["launches_timed"] else elapsed / args.steps * 1e3) / 1e3
+        alg_bytes = 4.0 * W * rows0 * frames_per_launch  # rank 0's rows of the launch's frames
         achieved = alg_bytes / launch_s / 1e9
+        traffic, traffic_source = pmc_traffic(key, frames_per_launch) if world == 1 else (None, None)
+        if world == 1:
+            parallelism = (f"1 GPU, {B} frame(s) of the sequence per launch"
+                           + (f", {F} launches in flight" if F > 1 else ""))
+        elif sharded:
+            parallelism = (f"{world} GPUs, one process each: row shards ("
+                           + ("contiguous bands of 8-row stripes" if args.shard == "bands" else
+                              "8-row stripes dealt round-robin"
+                              + (f", rank 0 weighted x{args.root_weight}" if args.root_weight != 1 else ""))
+                           + f") of {frames_per_step} frames per step, gathered into rank 0's frames by grouped "
+                           "RCCL point-to-point over xGMI + stripe unpack")
+        else:
+            parallelism = (f"{world} GPUs x whole frames (frame-parallel, {B} per launch), one process per GPU, "
+                           + ("finished frames sent to rank 0 by grouped RCCL p2p" if args.deliver == "root"
+                              else "frames stay on the GPU that rendered them (no exchange step)"))
         out = {
             "metric": METRIC,
             "value": round(mpix, 2),
@@ -329,7 +474,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "weak" if (frames_mode or world == 1) else "strong",
+            "scaling": "strong" if (sharded and args.scaling == "strong") else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -337,37 +482,35 @@ def main():
                        "max_iterations": w.gui.max_iterations, "sdf_iters": w.iters[0],
                        "normal_iters": w.iters[1], "fold_iters": w.iters[2],
                        "encode": "srgb8" if args.encode else "unorm8",
-                       "camera": "orbit, one pose per frame" if args.orbit else "fixed",
-                       "frames_per_launch": B, "launches_in_flight": F,
-                       "parallelism": (
-                           f"1 GPU, {B} frame(s) of the sequence per launch"
-                           + (f", {F} launches in flight" if F > 1 else "") if world == 1 else
-                           (f"{world} GPUs x whole frames (frame-parallel, {B} per launch), one process per GPU, "
-                            + ("finished frames sent to rank 0 by grouped RCCL p2p" if args.deliver == "root"
-                               else "frames stay on the GPU that rendered them (no exchange step)")
-                            if frames_mode else
-                            f"{world} row bands per frame, one process per GPU, RCCL p2p gather to rank 0"))},
+                       "camera": "orbit, one pose per frame" if args.camera == "orbit" else "fixed",
+                       "frames_per_step": frames_per_step, "frames_per_launch": frames_per_launch,
+                       "launches_in_flight": F, "parallelism": parallelism},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": pmc_traffic(key, B) if world == 1 else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "kernel_ms": round(launch_s * 1e3, 5),
-                         "kernel_ms_min": round(kernel_min_ms, 5), "kernel_ms_max": round(kernel_max_ms, 5),
-                         "launches_timed": timed_launches,
+                         "kernel_ms_min": round(m["kernel_ms_min"], 5), "kernel_ms_max": round(m["kernel_ms_max"], 5),
+                         "launches_timed": m["launches_timed"],
                          "concurrent_launches": F,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
-            "per_rank_kernel_ms": [round(x, 5) for x in per_rank_ms],
+            "per_rank_kernel_ms": [round(x, 5) for x in per_rank_kernel_ms],
+            "per_rank_step_ms": [round(x, 5) for x in per_rank_step_ms],
         }
+        if secondary:
+            out["secondary"] = secondary
         if check is not None:
             out["gathered_frame_equals_single_gpu_frame"] = check
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
-            out["roofline"]["secondary"] = work_count(w, launch_s / B)
+            out["roofline"]["secondary"] = work_count(w, launch_s / frames_per_launch)
         print(json.dumps(out), flush=True)
 
     for g in gss:
         g.close()
     if world > 1:
         dist.destroy_process_group()
+    if check is False:
+        sys.exit("bench.py: gathered frames differ from single-GPU frames")
 
 
 if __name__ == "__main__":

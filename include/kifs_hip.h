@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define KIFS_ABI_VERSION 1
+#define KIFS_ABI_VERSION 2
 
 /* ---- uniform images (data.rs:17-49) --------------------------------------- */
 
@@ -97,7 +97,7 @@ typedef enum KifsStatus {
     KIFS_ERR_BAD_SIZE = 3,     /* ~ RenderError::SurfaceMissized; zero size (render.rs:211) */
     KIFS_ERR_UNCONFIGURED = 4, /* render before all three uniforms were set */
     KIFS_ERR_RUNTIME = 5,      /* HIP error: fatal for the context */
-    KIFS_ERR_COMM = 6,         /* RCCL error */
+    KIFS_ERR_COMM = 6,         /* an inter-GPU transfer failed (kifs_multi_render's peer copies) */
     KIFS_ERR_BAD_ARG = 7       /* null pointer, unknown enum value, bad range */
 } KifsStatus;
 
@@ -170,7 +170,7 @@ int kifs_render_async(kifs_ctx* ctx, void* hip_stream, uint8_t* dev_out_rgba8,
  * idle -- its run time is the critical path of a few long rays -- and the workgroups of a batch
  * are interleaved frame by frame, so the long rays of all its frames march side by side.
  * Every frame is bit-identical to the same frame rendered alone. */
-#define KIFS_MAX_BATCH 8
+#define KIFS_MAX_BATCH 32
 int kifs_render_batch_async(kifs_ctx* ctx, void* hip_stream, int count,
                             const KifsCameraUniform* cameras, uint8_t* const* dev_outs_rgba8,
                             size_t pitch_bytes, int y0, int y1, int encode);
@@ -178,6 +178,45 @@ int kifs_render_batch_async(kifs_ctx* ctx, void* hip_stream, int count,
 /* Contiguous row-band partition used for multi-GPU frames: rank r
  * of `world` owns rows [y0, y1); bands differ by at most one row. */
 int kifs_band_range(int height, int rank, int world, int* y0, int* y1);
+
+/* ---- row shards: load-balanced multi-GPU partition ----------------------------
+ * Pixels are independent (entry.wgsl:49-59), so any set of rows can be rendered anywhere.  The
+ * expensive rows of these scenes sit in the middle of the frame (the projected bounding sphere), so
+ * contiguous bands leave the outer ranks idle.  A row SHARD is instead a list of 8-row stripes
+ * (KIFS_STRIPE_ROWS = the height of the kernels' 32 x 8 pixel tiles) dealt to the ranks in turn:
+ * stripe s covers frame rows [8 s, min(H, 8 s + 8)).
+ *
+ * kifs_shard_stripes: the stripes of `rank` when the frame's stripes are dealt to `world` ranks by
+ * smooth weighted round robin -- weights NULL: equal shares, rank r gets stripes r, r + world, ..;
+ * weights[r] >= 0: rank r gets weights[r] stripes in every sum(weights), spread evenly (a root that
+ * receives everybody else's rows over point-to-point xGMI links can be given a larger share, so
+ * that the peers' transfers take as long as the root's rendering).  Writes the ascending stripe
+ * indices to stripes[0 .. *n_stripes) (stripes may be NULL to only count) and the shard's total row
+ * count to *rows.  Every rank computes every rank's list from the same arguments.
+ *
+ * kifs_render_shard_async: kifs_render_batch_async for a shard.  Frame i (cameras[i]; cameras NULL
+ * with count 1 = the context's camera) is rendered into dev_outs[i]:
+ *   in_place == 0: a PACKED shard -- stripe k of the list occupies rows [8 k, 8 k + 8) of the
+ *                  buffer (n_rows x pitch_bytes: what a peer sends to the root in one message);
+ *   in_place != 0: dev_outs[i] is a whole frame and every row lands at its frame position (the
+ *                  root's own shard needs no copy).
+ * Pixel coordinates are global either way: shards are bit-identical to the frame's rows.
+ *
+ * kifs_unpack_shard_async: the root's side of the gather.  Copies `count` packed shards
+ * (dev_shards + i * shard_stride, rows shard_pitch apart) into the frames dev_frames + i *
+ * frame_stride (rows frame_pitch apart), stripe k to frame rows [8 stripes[k], ..).  Frame size from
+ * the context's screen; all strides in bytes, multiples of 4. */
+#define KIFS_STRIPE_ROWS 8
+int kifs_shard_stripes(int height, int world, const int* weights, int rank, int* stripes,
+                       int max_stripes, int* n_stripes, int* rows);
+int kifs_render_shard_async(kifs_ctx* ctx, void* hip_stream, int count,
+                            const KifsCameraUniform* cameras, uint8_t* const* dev_outs_rgba8,
+                            size_t pitch_bytes, const int* stripes, int n_stripes, int in_place,
+                            int encode);
+int kifs_unpack_shard_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t* dev_frames,
+                            size_t frame_pitch, size_t frame_stride, const uint8_t* dev_shards,
+                            size_t shard_pitch, size_t shard_stride, const int* stripes,
+                            int n_stripes);
 
 /* ---- single-process multi-GPU ------------------------------------------------------
  * For a host that drives all GPUs of a node from one process (the reference's host is one

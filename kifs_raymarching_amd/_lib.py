@@ -78,6 +78,12 @@ SIGNATURES = {
     "kifs_render_batch_async": (C.c_int, [_ctx, C.c_void_p, C.c_int, _P(CameraUniform),
                                           _P(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "kifs_band_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "kifs_shard_stripes": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), C.c_int, _P(C.c_int), C.c_int,
+                                     _P(C.c_int), _P(C.c_int)]),
+    "kifs_render_shard_async": (C.c_int, [_ctx, C.c_void_p, C.c_int, _P(CameraUniform), _P(C.c_void_p),
+                                          C.c_size_t, _P(C.c_int), C.c_int, C.c_int, C.c_int]),
+    "kifs_unpack_shard_async": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t,
+                                          C.c_void_p, C.c_size_t, C.c_size_t, _P(C.c_int), C.c_int]),
     "kifs_multi_create": (_ctx, [_P(C.c_int), C.c_int, _P(C.c_int)]),
     "kifs_multi_destroy": (None, [_ctx]),
     "kifs_multi_set_screen": (C.c_int, [_ctx, _P(ScreenUniform)]),
@@ -156,7 +162,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.kifs_abi_version() != 1:
+    if lib.kifs_abi_version() != 2:
         raise ImportError("libkifs_hip.so: ABI version mismatch")
     return lib
 

@@ -28,11 +28,21 @@ static_assert(offsetof(KifsOptionsUniform, background_color) == 32, "background_
 static_assert(offsetof(KifsOptionsUniform, is_heatmap) == 44, "is_heatmap at 44");
 static_assert(offsetof(KifsOptionsUniform, power) == 56, "power at 56");
 static_assert(offsetof(KifsOptionsUniform, constant) == 64, "constant at 64");
+static_assert(sizeof(kifs::BatchParams) <= 4096, "the kernel argument segment is limited to 4 KB");
+static_assert(KIFS_STRIPE_ROWS == kifs::TILE_H, "a stripe is one row of the kernels' tiles");
+
+// A row shard is a list of 8-row stripes of the frame (kifs_shard_stripes); its device image --
+// first frame row of every stripe -- is cached per context (a root unpacks the shards of every peer).
+struct RowTable {
+    std::vector<int> stripes;  // stripe indices, ascending
+    uint32_t* d_rows = nullptr;
+};
 
 // Tile order tables are keyed by the geometry they were built for and kept on the
-// device; a context alternates between very few geometries (full frame, its band).
+// device; a context alternates between very few geometries (full frame, its band or shard).
 struct TileTable {
     int width = 0, height = 0, y0 = 0, y1 = 0;
+    const RowTable* rows = nullptr;   // non-null: the table of a row shard (then y0 = 0, y1 = height)
     uint32_t* d_order = nullptr;      // order used by the next launch
     uint32_t* d_order_alt = nullptr;  // the other half of the double buffer (the sort's target)
     uint32_t* d_cost[2] = {nullptr, nullptr};  // per-tile cost, written by launch k into [k & 1]
@@ -50,6 +60,7 @@ constexpr int MAX_TILE_TABLES = 8;
 struct kifs_ctx {
     int device = 0;
     TileTable tables[MAX_TILE_TABLES];
+    std::vector<RowTable*> row_tables;  // never evicted while the context lives (a few hundred bytes each)
     uint64_t use_clock = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // tile-order sorts run here, beside the renders
@@ -220,6 +231,8 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->width = w;
     P->y0 = 0;
     P->y1 = h;
+    P->stripe_rows = nullptr;
+    P->out_frame_rows = 0;
     P->encode = KIFS_ENCODE_SRGB;
     P->pitch_words = uint32_t(w);
     P->out = nullptr;
@@ -266,17 +279,44 @@ static int tile_feedback_mode() {
 // Order in which workgroups take tiles: nearest to the frame centre first (squared
 // distance of the tile centre, ties by row then column), so the long rays start first.
 // Tiles are TILE_W x TILE_H pixels; rows are counted from the top of the band.
-TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
+// Device image of a stripe list, cached by content.  Stripes must be ascending and inside the frame.
+const RowTable* row_table(kifs_ctx* c, const int* stripes, int n, int height) {
+    for (const RowTable* r : c->row_tables)
+        if (int(r->stripes.size()) == n && std::equal(stripes, stripes + n, r->stripes.begin())) return r;
+    std::vector<uint32_t> rows(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) {
+        if (stripes[i] < 0 || int64_t(stripes[i]) * kifs::TILE_H >= height || (i > 0 && stripes[i] <= stripes[i - 1]))
+            return nullptr;
+        rows[size_t(i)] = uint32_t(stripes[i]) * uint32_t(kifs::TILE_H);
+    }
+    if (c->row_tables.size() >= 4096) return nullptr;  // a caller inventing a new partition every frame
+    RowTable* r = new (std::nothrow) RowTable();
+    if (!r) return nullptr;
+    r->stripes.assign(stripes, stripes + n);
+    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&r->d_rows), std::max<size_t>(rows.size(), 1) * sizeof(uint32_t)),
+                "hipMalloc(stripe rows)") ||
+        (n > 0 && !hip_ok(hipMemcpy(r->d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+                          "hipMemcpy(stripe rows)"))) {
+        if (r->d_rows) (void)hipFree(r->d_rows);
+        delete r;
+        return nullptr;
+    }
+    c->row_tables.push_back(r);
+    return r;
+}
+
+// `rows` non-null: the table of a row shard (tile row j = stripe rows->stripes[j]; y0 = 0, y1 = height).
+TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1, const RowTable* rows = nullptr) {
     TileTable* slot = nullptr;
     for (auto& t : c->tables) {
-        if (t.d_order && t.width == width && t.height == height && t.y0 == y0 && t.y1 == y1) {
+        if (t.d_order && t.width == width && t.height == height && t.y0 == y0 && t.y1 == y1 && t.rows == rows) {
             t.last_use = ++c->use_clock;
             return &t;
         }
         if (!slot || t.last_use < slot->last_use) slot = &t;
     }
     const int tx = (width + kifs::TILE_W - 1) / kifs::TILE_W;
-    const int ty = (y1 - y0 + kifs::TILE_H - 1) / kifs::TILE_H;
+    const int ty = rows ? int(rows->stripes.size()) : (y1 - y0 + kifs::TILE_H - 1) / kifs::TILE_H;
     if (tx > 0xffff || ty > 0xffff) return nullptr;
     struct Key { int64_t d2; uint32_t id; };
     std::vector<Key> keys;
@@ -285,7 +325,9 @@ TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
         for (int i = 0; i < tx; ++i) {
             // doubled coordinates keep everything in integers
             int64_t cx = int64_t(2 * i + 1) * kifs::TILE_W - width;
-            int64_t cy = int64_t(2 * j + 1) * kifs::TILE_H + 2 * int64_t(y0) - height;
+            const int64_t first = rows ? int64_t(rows->stripes[size_t(j)]) * kifs::TILE_H
+                                       : int64_t(y0) + int64_t(j) * kifs::TILE_H;  // the tile's first frame row
+            int64_t cy = 2 * first + kifs::TILE_H - height;
             keys.push_back({cx * cx + cy * cy, (uint32_t(j) << 16) | uint32_t(i)});
         }
     std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
@@ -313,6 +355,7 @@ TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1) {
         return nullptr;
     }
     slot->width = width; slot->height = height; slot->y0 = y0; slot->y1 = y1;
+    slot->rows = rows;
     slot->count = uint32_t(order.size());
     slot->last_use = ++c->use_clock;
     return slot;
@@ -348,8 +391,11 @@ int residency_for(const kifs::FrameParams& P, uint32_t group, int frame_height, 
 
 // One launch: `count` frames (count == 1: the context's camera; count > 1: cameras[i] -> outs[i])
 // sharing everything else.
+// `stripes` non-null: the launch renders that row shard (y0 = 0, y1 = height) instead of a band, into
+// packed rows (in_place == 0) or at the rows' frame positions (in_place != 0).
 int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUniform* cameras,
-                  uint8_t* const* outs, size_t pitch, int y0, int y1, int encode) {
+                  uint8_t* const* outs, size_t pitch, int y0, int y1, int encode,
+                  const int* stripes = nullptr, int n_stripes = 0, int in_place = 0) {
     hip_ok(hipGetLastError(), "stale error before enqueue");
     if (!c->have_screen || !c->have_options || (!c->have_camera && !cameras)) return KIFS_ERR_UNCONFIGURED;
     if (count < 1 || count > kifs::MAX_BATCH || !outs) return KIFS_ERR_BAD_ARG;
@@ -402,7 +448,15 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     P.pitch_words = uint32_t(pitch >> 2);
     P.out = reinterpret_cast<uint32_t*>(dev_out);
     if (y1 == y0) return KIFS_OK;
-    TileTable* tt = tile_table(c, P.width, h, y0, y1);
+    const RowTable* rows = nullptr;
+    if (stripes) {
+        if (n_stripes == 0) return KIFS_OK;
+        rows = row_table(c, stripes, n_stripes, h);
+        if (!rows) return KIFS_ERR_BAD_ARG;
+        P.stripe_rows = rows->d_rows;
+        P.out_frame_rows = in_place ? 1 : 0;
+    }
+    TileTable* tt = tile_table(c, P.width, h, y0, y1, rows);
     if (!tt) return KIFS_ERR_RUNTIME;
     // Temporal feedback on the tile order.  A launch can leave a cost per tile (the run time of
     // the tile's slowest wave); a one-workgroup counting sort on the context's side stream turns
@@ -452,8 +506,11 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     // two contexts fell back to running one after the other).  The 10 us then hide behind the
     // other frames' kernels.  A lone frame keeps the side stream: there nothing else can.
     const bool inline_sort = c->frames_in_flight > 1 || count > 1;
-    if (use_feedback && inline_sort && tt->sort_pending) {
-        // a side-stream sort from earlier lone launches still owns d_order_alt: take its result first
+    if (use_feedback && tt->sort_pending && (inline_sort || k != 2)) {
+        // A side-stream sort from earlier launches still owns d_cost[0] and d_order_alt -- lone launches
+        // before a batch, or a period cut short when feedback was switched off in between (options
+        // changed to a pipeline without it and back).  Take its result before anything here records
+        // costs or sorts again: the sort reads cost[] twice and must not see it change.
         if (!hip_ok(hipStreamWaitEvent(stream, tt->sorted, 0), "wait(sorted)")) return KIFS_ERR_RUNTIME;
         std::swap(tt->d_order, tt->d_order_alt);
         tt->sort_pending = false;
@@ -520,8 +577,7 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         ++c->prof_count;
     }
     if (!use_feedback) {  // no bookkeeping, no events: nothing depends on this launch
-        tt->launches = 0;
-        tt->sort_pending = false;
+        tt->launches = 0;  // (a pending side-stream sort stays pending: the next feedback launch waits for it)
         return KIFS_OK;
     }
     tt->launches += 1;
@@ -568,7 +624,7 @@ const char* kifs_strerror(int status) {
     case KIFS_ERR_BAD_SIZE: return "bad frame size or pitch";
     case KIFS_ERR_UNCONFIGURED: return "render before screen, camera and options were set";
     case KIFS_ERR_RUNTIME: return "HIP runtime error";
-    case KIFS_ERR_COMM: return "RCCL communication error";
+    case KIFS_ERR_COMM: return "inter-GPU transfer failed (peer copy over xGMI)";
     case KIFS_ERR_BAD_ARG: return "bad argument";
     default: return "unknown status";
     }
@@ -615,6 +671,10 @@ void kifs_destroy(kifs_ctx* c) {
     }
     for (auto& t : c->tables)
         if (t.d_order) free_table(t);
+    for (RowTable* r : c->row_tables) {
+        if (r->d_rows) (void)hipFree(r->d_rows);
+        delete r;
+    }
     for (hipEvent_t ev : c->prof_a) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->prof_b) if (ev) (void)hipEventDestroy(ev);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -675,6 +735,79 @@ int kifs_band_range(int height, int rank, int world, int* y0, int* y1) {
     *y0 = int(h * rank / world);
     *y1 = int(h * (rank + 1) / world);
     return KIFS_OK;
+}
+
+int kifs_shard_stripes(int height, int world, const int* weights, int rank, int* stripes, int max_stripes,
+                       int* n_stripes, int* rows) {
+    if (height < 0 || world <= 0 || world > 1024 || rank < 0 || rank >= world || !n_stripes) return KIFS_ERR_BAD_ARG;
+    long long total = 0;
+    for (int r = 0; r < world; ++r) {
+        const int w = weights ? weights[r] : 1;
+        if (w < 0 || w > (1 << 20)) return KIFS_ERR_BAD_ARG;
+        total += w;
+    }
+    if (total <= 0) return KIFS_ERR_BAD_ARG;
+    // Smooth weighted round robin: every stripe goes to the rank with the largest running credit;
+    // equal weights deal 0, 1, .., world-1, 0, 1, ..; a rank of weight w gets w stripes in every
+    // `total`, spread evenly through the frame (the expensive rows sit in its middle).
+    std::vector<long long> credit(static_cast<size_t>(world), 0);
+    const int all = (height + KIFS_STRIPE_ROWS - 1) / KIFS_STRIPE_ROWS;
+    int n = 0, nrows = 0;
+    for (int s = 0; s < all; ++s) {
+        int best = 0;
+        for (int r = 0; r < world; ++r) {
+            credit[size_t(r)] += weights ? weights[r] : 1;
+            if (credit[size_t(r)] > credit[size_t(best)]) best = r;
+        }
+        credit[size_t(best)] -= total;
+        if (best != rank) continue;
+        if (stripes) {
+            if (n >= max_stripes) return KIFS_ERR_BAD_ARG;
+            stripes[n] = s;
+        }
+        ++n;
+        nrows += std::min(KIFS_STRIPE_ROWS, height - s * KIFS_STRIPE_ROWS);
+    }
+    *n_stripes = n;
+    if (rows) *rows = nrows;
+    return KIFS_OK;
+}
+
+int kifs_render_shard_async(kifs_ctx* c, void* hip_stream, int count, const KifsCameraUniform* cameras,
+                            uint8_t* const* dev_outs, size_t pitch, const int* stripes, int n_stripes,
+                            int in_place, int encode) {
+    if (!c || !dev_outs || !stripes || n_stripes < 0 || (!cameras && count != 1)) return KIFS_ERR_BAD_ARG;
+    if (!c->have_screen) return KIFS_ERR_UNCONFIGURED;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    int w, h;
+    int st = frame_dims(c, &w, &h);
+    if (st != KIFS_OK) return st;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return enqueue_batch(c, s, count, cameras, dev_outs, pitch, 0, h, encode, stripes, n_stripes, in_place);
+}
+
+int kifs_unpack_shard_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch,
+                            size_t frame_stride, const uint8_t* dev_shards, size_t shard_pitch,
+                            size_t shard_stride, const int* stripes, int n_stripes) {
+    if (!c || !dev_frames || !dev_shards || !stripes || n_stripes < 0 || count < 0) return KIFS_ERR_BAD_ARG;
+    if (!c->have_screen) return KIFS_ERR_UNCONFIGURED;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    int w, h;
+    int st = frame_dims(c, &w, &h);
+    if (st != KIFS_OK) return st;
+    const size_t row_bytes = size_t(w) * 4;
+    if (frame_pitch < row_bytes || shard_pitch < row_bytes || ((frame_pitch | shard_pitch | frame_stride | shard_stride) & 3u) ||
+        ((reinterpret_cast<uintptr_t>(dev_frames) | reinterpret_cast<uintptr_t>(dev_shards)) & 3u))
+        return KIFS_ERR_BAD_SIZE;
+    if (n_stripes == 0 || count == 0) return KIFS_OK;
+    const RowTable* rows = row_table(c, stripes, n_stripes, h);
+    if (!rows) return KIFS_ERR_BAD_ARG;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return hip_ok(kifs::launch_unpack_stripes(dev_frames, frame_pitch, frame_stride, dev_shards, shard_pitch,
+                                              shard_stride, rows->d_rows, n_stripes, count, w, h, s),
+                  "unpack_stripes_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;
 }
 
 int kifs_render_async(kifs_ctx* c, void* hip_stream, uint8_t* dev_out, size_t pitch, int y0,

@@ -12,6 +12,11 @@ hipError_t launch_render(const BatchParams& B, uint32_t group, uint32_t primitiv
 // Device-side counting sort: order[] = tile ids (x | y << 16) by descending cost[]; clears cost[].
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_count,
                              uint32_t tiles_x, hipStream_t stream);
+// Packed row shards -> frame rows: stripe s of shard f (8 rows at src + f * src_shard_stride + 8 s *
+// src_pitch) goes to frame rows stripe_rows[s].. of dst + f * dst_frame_stride.
+hipError_t launch_unpack_stripes(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint8_t* src,
+                                 size_t src_pitch, size_t src_shard_stride, const uint32_t* stripe_rows,
+                                 int n_stripes, int count, int width, int height, hipStream_t stream);
 hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,
                               const float* pts, int n, float* sdf, float* nrm,
                               hipStream_t stream);

@@ -1,7 +1,7 @@
 // kifs_kernels.hip -- gfx950 kernels of the raymarching library and their launchers.
 //
 // Three render kernels, all 256-thread workgroups over 32 x 8 pixel tiles taken from a tile ORDER
-// table, all fed by the kernel argument (BatchParams: frame constants + up to 8 views; scalar loads ->
+// table, all fed by the kernel argument (BatchParams: frame constants + up to 32 views; scalar loads ->
 // SGPRs), all storing encoded pixels through an LDS tile so that every wave-level store instruction
 // writes two full 128-byte row segments:
 //   render_kernel<GROUP, PRIM>          the latency path: each wave owns an 8 x 8 block of its tile and
@@ -46,6 +46,16 @@ __device__ __forceinline__ FrameParams batch_frame(const BatchParams& B, uint32_
     return P;
 }
 
+// Frame row at which local tile row `tile_row` of the launch starts: a contiguous band counts on
+// from y0, a row shard looks its stripe up (scalar load: tile_row is uniform per workgroup).
+__device__ __forceinline__ int tile_frame_row(const FrameParams& P, uint32_t tile_row) {
+    return P.stripe_rows ? int(P.stripe_rows[tile_row]) : P.y0 + int(tile_row) * TILE_H;
+}
+// Row of the destination for frame row `y` = row `local` of the launch's rows.
+__device__ __forceinline__ size_t out_row(const FrameParams& P, int y, int local) {
+    return size_t(P.out_frame_rows ? y : local);
+}
+
 // True when no pixel of this wave can ever be hit: every valid lane's ray passes the origin at more
 // than sqrt(1.2) (B + epsilon), B the scene's bounding radius (fill_params).  Same geometry as
 // ray_never_inside, but on the unnormalised direction and an approximate uv (28 instructions, no
@@ -88,9 +98,10 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
     const int ly = lane >> 3;
     const uint32_t tile = P.tile_order[slot];  // scalar load: uniform per workgroup
     const int tile_x = int(tile & 0xffffu) * TILE_W;
-    const int tile_y = int(tile >> 16) * TILE_H;     // row offset within the band
+    const int tile_y = int(tile >> 16) * TILE_H;     // row offset within the launch's rows
+    const int frame_y = tile_frame_row(P, tile >> 16);  // the tile's first frame row
     const int x = tile_x + lx;
-    const int y = P.y0 + tile_y + ly;
+    const int y = frame_y + ly;
     const bool valid = (x < P.width) && (y < P.y1);
 
     const bool feedback = P.tile_cost != nullptr;  // wave-uniform
@@ -141,9 +152,8 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
     // store mapping: thread -> (tid & 31, tid >> 5): linear rows of 128 bytes
     const int sx = tid & (TILE_W - 1), sy = tid >> 5;
     const int ox = tile_x + sx;
-    const int oy = tile_y + sy;  // row within the band
-    if (ox < P.width && (P.y0 + oy) < P.y1)
-        P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
+    if (ox < P.width && (frame_y + sy) < P.y1)
+        P.out[out_row(P, frame_y + sy, tile_y + sy) * P.pitch_words + ox] = s_tile[sy][sx];
 }
 
 // render_group_kernel<GROUP, PRIM, T>: the throughput path.  A workgroup renders T consecutive
@@ -170,6 +180,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     __shared__ float s_srgb[256];
     __shared__ uint32_t s_tile[T][TILE_H][TILE_W];
     __shared__ uint32_t s_tiles[T];  // the group's tiles (x | y << 16), 0xffffffff past the table's end
+    __shared__ int s_rows[T];        // first frame row of each of them
     // queue entry: pixel (tile-in-group << 8 | ly << 5 | lx), t, direction
     __shared__ uint32_t q_pix[2][CAP];
     __shared__ float q_t[2][CAP], q_dx[2][CAP], q_dy[2][CAP], q_dz[2][CAP];
@@ -199,7 +210,9 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     }
     if (tid < T) {
         const uint32_t ti = group * uint32_t(T) + uint32_t(tid);
-        s_tiles[tid] = ti < P.tile_count ? P.tile_order[ti] : 0xffffffffu;
+        const uint32_t tile = ti < P.tile_count ? P.tile_order[ti] : 0xffffffffu;
+        s_tiles[tid] = tile;
+        s_rows[tid] = tile != 0xffffffffu ? tile_frame_row(P, tile >> 16) : 0;
     }
 #pragma unroll
     for (int j = 0; j < T; ++j) s_tile[j][ly][lx] = P.background_rgba;
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
         const uint32_t tile = s_tiles[j];  // uniform
         if (tile == 0xffffffffu) break;
         const int x = int(tile & 0xffffu) * TILE_W + lx;
-        const int y = P.y0 + int(tile >> 16) * TILE_H + ly;
+        const int y = s_rows[j] + ly;
         const bool valid = (x < P.width) && (y < P.y1);
         if (wave_is_culled(P, x, y, valid) || __ballot(valid) == 0ull) continue;  // wave-uniform
         const V3 dir = ray_direction(P, x, y);
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             const float t = h_t[i];
             const uint32_t tile = s_tiles[pix >> 8];
             const int hx = int(pix & 31u), hy = int((pix >> 5) & 7u);
-            const V3 dir = ray_direction(P, int(tile & 0xffffu) * TILE_W + hx, P.y0 + int(tile >> 16) * TILE_H + hy);
+            const V3 dir = ray_direction(P, int(tile & 0xffffu) * TILE_W + hx, s_rows[pix >> 8] + hy);
             const V3 p = (t == 0.0f) ? P.origin
                                      : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
                                           fmaf_(t, dir.z, P.origin.z)};
@@ -351,8 +364,9 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
         const uint32_t tile = s_tiles[j];
         if (tile == 0xffffffffu) break;
         const int ox = int(tile & 0xffffu) * TILE_W + sx;
-        const int oy = int(tile >> 16) * TILE_H + sy;  // row within the band
-        if (ox < P.width && (P.y0 + oy) < P.y1) P.out[size_t(oy) * P.pitch_words + ox] = s_tile[j][sy][sx];
+        const int oy = int(tile >> 16) * TILE_H + sy;  // row within the launch's rows
+        const int fy = s_rows[j] + sy;                 // row of the frame
+        if (ox < P.width && fy < P.y1) P.out[out_row(P, fy, oy) * P.pitch_words + ox] = s_tile[j][sy][sx];
         if (tid == 0 && feedback) {
             uint32_t* slot = &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)];
             if (batch > 1) atomicMax(slot, cost);  // the batch's views share the table (the sort clears it)
@@ -384,9 +398,10 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const BatchPar
     const uint32_t tile = P.tile_order[block >> 2];
     const int sub = int(block & 3u);
     const int tile_x = int(tile & 0xffffu) * TILE_W;
-    const int tile_y = int(tile >> 16) * TILE_H + 2 * sub;  // row offset within the band
+    const int tile_y = int(tile >> 16) * TILE_H + 2 * sub;  // row offset within the launch's rows
+    const int frame_y = tile_frame_row(P, tile >> 16) + 2 * sub;
     const int x = tile_x + lx;
-    const int y = P.y0 + tile_y + ly;
+    const int y = frame_y + ly;
     const bool valid = (x < P.width) && (y < P.y1);
 
     V3 colour{0.0f, 0.0f, 0.0f};
@@ -417,8 +432,8 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const BatchPar
     if (tid < 2 * TILE_W) {
         const int sx = tid & (TILE_W - 1), sy = tid >> 5;
         const int ox = tile_x + sx;
-        const int oy = tile_y + sy;
-        if (ox < P.width && (P.y0 + oy) < P.y1) P.out[size_t(oy) * P.pitch_words + ox] = s_tile[sy][sx];
+        if (ox < P.width && (frame_y + sy) < P.y1)
+            P.out[out_row(P, frame_y + sy, tile_y + sy) * P.pitch_words + ox] = s_tile[sy][sx];
     }
 }
 
@@ -576,6 +591,48 @@ hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_coun
                              uint32_t tiles_x, hipStream_t stream) {
     if (tile_count == 0) return hipSuccess;
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, tile_count, tiles_x);
+    return hipGetLastError();
+}
+
+// ---- row shards: packed stripes -> frame rows (the root's side of the multi-GPU gather) ----
+// Workgroup (s, f): stripe s of shard f.  Row k of stripe s sits at packed row 8 s + k and goes to
+// frame row stripe_rows[s] + k.  Rows are copied 16 bytes per lane when everything is aligned.
+__global__ __launch_bounds__(256) void unpack_stripes_kernel(
+    uint8_t* __restrict__ dst, size_t dst_pitch, size_t dst_frame_stride, const uint8_t* __restrict__ src,
+    size_t src_pitch, size_t src_shard_stride, const uint32_t* __restrict__ stripe_rows, int row_bytes,
+    int height, int vec16) {
+    const uint32_t s = blockIdx.x, f = blockIdx.y;
+    const int y0 = int(stripe_rows[s]);
+    const int rows = min(TILE_H, height - y0);
+    const uint8_t* from = src + size_t(f) * src_shard_stride + size_t(s) * TILE_H * src_pitch;
+    uint8_t* to = dst + size_t(f) * dst_frame_stride + size_t(y0) * dst_pitch;
+    if (vec16) {
+        const int per_row = row_bytes >> 4;
+        for (int i = threadIdx.x; i < rows * per_row; i += 256) {
+            const int r = i / per_row, c = i - r * per_row;
+            reinterpret_cast<uint4*>(to + size_t(r) * dst_pitch)[c] =
+                reinterpret_cast<const uint4*>(from + size_t(r) * src_pitch)[c];
+        }
+    } else {
+        const int per_row = row_bytes >> 2;
+        for (int i = threadIdx.x; i < rows * per_row; i += 256) {
+            const int r = i / per_row, c = i - r * per_row;
+            reinterpret_cast<uint32_t*>(to + size_t(r) * dst_pitch)[c] =
+                reinterpret_cast<const uint32_t*>(from + size_t(r) * src_pitch)[c];
+        }
+    }
+}
+
+hipError_t launch_unpack_stripes(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint8_t* src,
+                                 size_t src_pitch, size_t src_shard_stride, const uint32_t* stripe_rows,
+                                 int n_stripes, int count, int width, int height, hipStream_t stream) {
+    if (n_stripes <= 0 || count <= 0) return hipSuccess;
+    const int row_bytes = width * 4;
+    const uintptr_t all = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | dst_pitch |
+                          dst_frame_stride | src_pitch | src_shard_stride | uintptr_t(row_bytes);
+    hipLaunchKernelGGL(unpack_stripes_kernel, dim3(uint32_t(n_stripes), uint32_t(count)), dim3(256), 0, stream, dst,
+                       dst_pitch, dst_frame_stride, src, src_pitch, src_shard_stride, stripe_rows, row_bytes, height,
+                       (all & 15u) == 0 ? 1 : 0);
     return hipGetLastError();
 }
 

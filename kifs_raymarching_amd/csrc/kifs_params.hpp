@@ -40,6 +40,13 @@ struct FrameParams {
     int shadow_steps;
     float shadow_k, shadow_t0, shadow_max_t;
     int width, y0, y1;                  // frame width, row band [y0, y1)
+    // Row shards (multi-GPU): when non-null, local tile row j of the launch is the 8-row stripe that
+    // starts at frame row stripe_rows[j] (device table; y0 = 0, y1 = frame height); when null, tile
+    // row j starts at frame row y0 + 8 j (a contiguous band).
+    const uint32_t* stripe_rows;
+    // 0: row k of the launch's rows goes to out + k * pitch (a packed band or shard);
+    // 1: every row goes to its FRAME position, out + y * pitch (a shard rendered in place).
+    int out_frame_rows;
     int encode;                         // KifsEncode
     uint32_t pitch_words;               // output row pitch in 32-bit words
     uint32_t* out;                      // first row of the band
@@ -67,8 +74,9 @@ struct FrameParams {
 
 // A launch renders a batch of up to MAX_BATCH frames that share screen, options and tile
 // order and differ in camera and destination (the frames of an orbit).  One frame's run time
-// is the critical path of a few long rays with most SIMDs idle; a batch fills them.
-constexpr int MAX_BATCH = 8;
+// is the critical path of a few long rays with most SIMDs idle; a batch fills them.  The views
+// travel in the kernel argument (56 B each: 2.1 KB with the frame constants, limit 4 KB).
+constexpr int MAX_BATCH = 32;
 struct BatchView {
     V3 origin, m0, m1, m2;  // CameraUniform of this frame
     uint32_t* out;          // first row of its band

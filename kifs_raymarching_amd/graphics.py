@@ -19,7 +19,8 @@ import numpy as np
 
 from . import _lib
 
-MAX_BATCH = 8  # KIFS_MAX_BATCH of include/kifs_hip.h
+MAX_BATCH = 32  # KIFS_MAX_BATCH of include/kifs_hip.h
+STRIPE_ROWS = 8  # KIFS_STRIPE_ROWS
 from ._lib import (CameraDataC, CameraUniform, ExtensionsC, GuiDataC, KifsError, OptionsUniform,
                    ScreenUniform, check, lib)
 
@@ -264,8 +265,7 @@ class GraphicState:
             out = np.empty((rows, w, 4), dtype=np.uint8)
         pitch = pitch_bytes if pitch_bytes is not None else w * 4
         if isinstance(out, np.ndarray):
-            assert out.dtype == np.uint8 and out.flags.c_contiguous
-            assert out.size >= rows * w * 4 or rows == 0
+            _check_host_destination(out, rows, w, pitch)
             ptr = out.ctypes.data
         else:
             ptr = _device_pointer(out)
@@ -308,6 +308,43 @@ class GraphicState:
         ptrs = (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
         check(lib.kifs_render_batch_async(self._ctx, stream, n, cams, ptrs, pitch, y0, y1, encode),
               "render_batch_async")
+
+    def render_shard_async(self, outs, cameras, stripes, in_place: bool = False, stream=None,
+                           encode: int = ENCODE_SRGB, pitch_bytes: int = None):
+        """render_batch_async for a row shard (kifs_render_shard_async): `stripes` is the list of
+        8-row stripe indices (shard_stripes); outs[i] is a packed (rows, W, 4) device tensor, or
+        with in_place a whole (H, W, 4) frame whose shard rows are written where they belong."""
+        if len(outs) != len(cameras) or not (1 <= len(outs) <= MAX_BATCH):
+            raise ValueError(f"render_shard_async: 1..{MAX_BATCH} frames, one camera each")
+        w = self.screen_data.width
+        pitch = pitch_bytes if pitch_bytes is not None else w * 4
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+            if not stream:
+                raise ValueError("render_shard_async: pass a non-default torch.cuda.Stream")
+        n = len(outs)
+        cams = (CameraUniform * n)(*[c.into_buffer_data() if hasattr(c, "into_buffer_data") else c
+                                     for c in cameras])
+        ptrs = (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
+        st = _stripe_array(stripes)
+        check(lib.kifs_render_shard_async(self._ctx, stream, n, cams, ptrs, pitch, st, len(st),
+                                          1 if in_place else 0, encode), "render_shard_async")
+
+    def unpack_shard_async(self, frames, shards, stripes, stream=None):
+        """Root side of the gather (kifs_unpack_shard_async): `shards` (count, rows, W, 4) packed,
+        `frames` (count, H, W, 4); stripe k of every shard goes to frame rows 8 * stripes[k]...
+        Both are contiguous device tensors."""
+        w, h = self.screen_data.width, self.screen_data.height
+        count = int(frames.shape[0]) if frames.dim() == 4 else 1
+        rows = int(shards.shape[-3])
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+            if not stream:
+                raise ValueError("unpack_shard_async: pass a non-default torch.cuda.Stream")
+        st = _stripe_array(stripes)
+        check(lib.kifs_unpack_shard_async(self._ctx, stream, count, _device_pointer(frames), w * 4, h * w * 4,
+                                          _device_pointer(shards), w * 4, rows * w * 4, st, len(st)),
+              "unpack_shard_async")
 
     def debug_last_round_steps(self) -> int:
         """Round length of the ray re-queuing in the latest launch (0: one wave per block)."""
@@ -419,6 +456,8 @@ class MultiGraphicState:
         w, h = self.screen_data.width, self.screen_data.height
         if out is None:
             out = np.empty((h, w, 4), dtype=np.uint8)
+        if isinstance(out, np.ndarray):
+            _check_host_destination(out, h, w, pitch_bytes or w * 4)
         ptr = out.ctypes.data if isinstance(out, np.ndarray) else _device_pointer(out)
         check(lib.kifs_multi_render(self._m, ptr, pitch_bytes or w * 4, encode), "multi render")
         return out
@@ -447,6 +486,33 @@ class MultiGraphicState:
             self.close()
         except Exception:
             pass
+
+
+def _check_host_destination(out: np.ndarray, rows: int, width: int, pitch: int):
+    """A host destination must hold rows of `pitch` bytes: the library copies (rows-1)*pitch + 4*width
+    bytes into it and knows nothing about the array's size."""
+    if out.dtype != np.uint8 or not out.flags.c_contiguous:
+        raise ValueError("render: host destination must be a C-contiguous uint8 array")
+    if pitch < width * 4 or pitch % 4:
+        raise ValueError("render: pitch_bytes must be a multiple of 4 and at least 4 * width")
+    if rows > 0 and out.nbytes < (rows - 1) * pitch + width * 4:
+        raise ValueError(f"render: host destination of {out.nbytes} bytes is too small for {rows} rows "
+                         f"of pitch {pitch}")
+
+
+def _stripe_array(stripes):
+    return (C.c_int * len(stripes))(*[int(s) for s in stripes])
+
+
+def shard_stripes(height: int, rank: int, world: int, weights=None):
+    """kifs_shard_stripes: (stripe indices of `rank`, total rows) when the frame's 8-row stripes
+    are dealt to `world` ranks (weights None: equal shares = stripes rank, rank + world, ...)."""
+    cap = (height + STRIPE_ROWS - 1) // STRIPE_ROWS
+    buf = (C.c_int * max(cap, 1))()
+    n, rows = C.c_int(), C.c_int()
+    wts = None if weights is None else (C.c_int * world)(*[int(x) for x in weights])
+    check(lib.kifs_shard_stripes(height, world, wts, rank, buf, cap, C.byref(n), C.byref(rows)), "shard_stripes")
+    return list(buf[:n.value]), rows.value
 
 
 def band_range(height: int, rank: int, world: int):

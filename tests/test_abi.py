@@ -1,6 +1,7 @@
 """The C-ABI library loads without a GPU and exports every symbol include/kifs_hip.h
 declares; argument checking and the GPU-free entry points behave as documented."""
 import ctypes as C
+import os
 import re
 from pathlib import Path
 
@@ -20,7 +21,8 @@ def test_header_declares_the_expected_surface():
     names = declared_functions()
     for must in ("kifs_create", "kifs_destroy", "kifs_set_screen", "kifs_set_camera",
                  "kifs_set_options", "kifs_set_iters", "kifs_render", "kifs_render_async",
-                 "kifs_band_range", "kifs_last_kernel_ms", "kifs_strerror", "kifs_host_camera",
+                 "kifs_band_range", "kifs_shard_stripes", "kifs_render_shard_async", "kifs_unpack_shard_async",
+                 "kifs_render_batch_async", "kifs_last_kernel_ms", "kifs_strerror", "kifs_host_camera",
                  "kifs_host_options", "kifs_host_screen", "kifs_eval_points", "kifs_eval_math"):
         assert must in names
     assert len(names) >= 25
@@ -52,7 +54,7 @@ def test_header_compiles_as_c_and_sizes_match(tmp_path):
 
 def test_strerror_and_version(kifs):
     from kifs_raymarching_amd._lib import lib
-    assert lib.kifs_abi_version() == 1
+    assert lib.kifs_abi_version() == 2
     assert lib.kifs_strerror(0) == b"ok"
     msgs = {lib.kifs_strerror(i) for i in range(8)}
     assert len(msgs) == 8 and lib.kifs_strerror(99) == b"unknown status"
@@ -80,6 +82,13 @@ def test_null_and_bad_arguments_do_not_crash(kifs):
     assert lib.kifs_set_iters(None, 1, 1, 1) == 7
     assert lib.kifs_render(None, None, 0, 0, 0, 1) == 7
     assert lib.kifs_render_async(None, None, None, 0, 0, 0, 1) == 7
+    assert lib.kifs_render_shard_async(None, None, 1, None, None, 0, None, 0, 0, 1) == 7
+    assert lib.kifs_unpack_shard_async(None, None, 1, None, 0, 0, None, 0, 0, None, 0) == 7
+    n = C.c_int()
+    assert lib.kifs_shard_stripes(8, 2, None, 0, None, 0, None, None) == 7          # nowhere to report the count
+    assert lib.kifs_shard_stripes(64, 2, None, 0, None, 0, C.byref(n), None) == 0 and n.value == 4  # counting only
+    small = (C.c_int * 2)()
+    assert lib.kifs_shard_stripes(64, 2, None, 0, small, 2, C.byref(n), None) == 7  # list does not fit
     assert lib.kifs_synchronize(None) == 7
     assert lib.kifs_last_kernel_ms(None) < 0
     lib.kifs_destroy(None)  # no-op
@@ -118,3 +127,20 @@ def test_product_never_touches_the_oracle():
         if p.suffix in (".py", ".cpp", ".hip", ".hpp", ".h") or p.name == "Makefile":
             text = p.read_text()
             assert "oracle" not in text.lower(), p
+
+
+def test_bench_launches_its_own_ranks_and_reports_a_failed_rank():
+    """`python bench.py --gpus 2` without a launcher starts the two ranks itself (fresh child
+    processes, before anything touches a GPU).  In this container the ranks find no GPU and exit;
+    the parent must then exit non-zero and say so instead of hanging or printing a result."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU: here the ranks would run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "no GPU visible" in p.stderr and "a rank failed" in p.stderr
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())

@@ -191,3 +191,105 @@ def test_frame_stream_without_delivery_keeps_frames_local(tmp_path, oracle):
                 want = oracle.render(sc, oracle.camera_uniform(3.0, 0.2 * f, 0.1), opt, oracle.iters(100, 10, 6))
                 assert (stacks[k][i * height:(i + 1) * height] == want).all(), (rank, k, i)
     assert seen == set(range(2 * steps * world))
+
+
+# ---- row shards (interleaved stripes), batches of frames per step ---------------------------
+def _oracle_rows(O, sc, cam, opt, it, height, stripes):
+    """The rows of a shard, packed: what kifs_render_shard_async writes with in_place = 0."""
+    parts = [O.render(sc, cam, opt, it, y0=8 * s, y1=min(height, 8 * s + 8), nthreads=1) for s in stripes]
+    return np.concatenate(parts, axis=0)
+
+
+def _shard_worker(rank, world, port, width, height, steps, count, weights, contiguous, outdir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from kifs_raymarching_amd.bands import ShardFrames
+
+        sc = O.screen_uniform(width, height)
+        opt = O.options_from_gui(fractal_group=1, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=40)
+        it = O.iters(8, 4, 4)
+        sf = ShardFrames(width, height, rank, world, "cpu", frames_per_step=count, weights=weights,
+                         contiguous=contiguous)
+        every = sorted(s for st in sf.stripes for s in st)
+        assert every == list(range((height + 7) // 8)), "every stripe is dealt exactly once"
+
+        def render_shard(outs, first_frame, stripes, in_place):
+            assert in_place == (rank == 0) and len(outs) == count
+            for i, out in enumerate(outs):
+                cam = O.camera_uniform(3.0, 0.3 * (first_frame + i), 0.1)
+                rows = torch.from_numpy(_oracle_rows(O, sc, cam, opt, it, height, stripes))
+                if in_place:  # the root writes its rows at their frame positions
+                    y = 0
+                    for s in stripes:
+                        n = min(height, 8 * s + 8) - 8 * s
+                        out[8 * s:8 * s + n].copy_(rows[y:y + n])
+                        y += n
+                else:
+                    out.copy_(rows)
+
+        got = []
+        for k in range(steps):
+            sf.step(k, render_shard)
+            if k >= 1:
+                sf.wait(k - 1)
+                if rank == 0:
+                    got.append(sf.frames(k - 1).clone().numpy())
+        sf.wait_all()
+        if rank == 0:
+            got.append(sf.frames(steps - 1).clone().numpy())
+            np.save(os.path.join(outdir, "shards.npy"), np.concatenate(got, axis=0))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height,count,weights,contiguous", [
+    (2, 40, 2, None, False),       # 5 stripes over 2 ranks: 3 + 2
+    (3, 43, 2, None, False),       # 6 stripes, the last one 3 rows tall
+    (3, 52, 1, [3, 1, 1], False),  # a root that renders three stripes in five
+    (2, 44, 2, None, True),        # contiguous runs of stripes through the same machinery
+])
+def test_shard_gather_equals_single_frames(world, height, count, weights, contiguous, tmp_path, oracle):
+    """bench.py's default at N > 1: every rank renders its stripes of the step's frames, one message
+    per peer, the root unpacks; the gathered frames equal single-process frames."""
+    width, steps = 40, 3
+    mp.spawn(_shard_worker,
+             args=(world, _free_port(), width, height, steps, count, weights, contiguous, str(tmp_path)),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "shards.npy")
+    assert got.shape == (steps * count, height, width, 4)
+    sc = oracle.screen_uniform(width, height)
+    opt = oracle.options_from_gui(fractal_group=1, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=40)
+    for f in range(steps * count):
+        want = oracle.render(sc, oracle.camera_uniform(3.0, 0.3 * f, 0.1), opt, oracle.iters(8, 4, 4))
+        assert (got[f] == want).all(), f"frame {f} differs"
+    assert (got[0] != got[1]).any()
+
+
+def test_shard_stripes_partition(kifs):
+    """kifs_shard_stripes: equal weights deal r, r + world, ..; weights shift shares; every stripe
+    goes to exactly one rank; rows add up to the frame; bad arguments are refused."""
+    for height, world in [(1080, 8), (1081, 8), (4096, 8), (4320, 8), (7, 3), (8, 1), (100, 5)]:
+        all_stripes, total = [], 0
+        for r in range(world):
+            st, rows = kifs.shard_stripes(height, r, world)
+            assert st == list(range(r, (height + 7) // 8, world))
+            all_stripes += st
+            total += rows
+        assert sorted(all_stripes) == list(range((height + 7) // 8)) and total == height
+    w = [3, 1, 1, 1, 1, 1, 1, 1]
+    shares = [kifs.shard_stripes(1080, r, 8, w) for r in range(8)]
+    assert sorted(s for st, _ in shares for s in st) == list(range(135))
+    assert sum(rows for _, rows in shares) == 1080
+    assert abs(len(shares[0][0]) - 135 * 3 / 10) <= 1 and all(abs(len(st) - 13.5) <= 1 for st, _ in shares[1:])
+    gaps = np.diff(shares[0][0])
+    assert gaps.max() <= 5, "the root's stripes are spread through the frame, not clumped"
+    assert kifs.shard_stripes(64, 1, 2, [1, 0]) == ([], 0)  # a rank of weight 0 renders nothing
+    for bad in [dict(height=-1, rank=0, world=2), dict(height=8, rank=2, world=2), dict(height=8, rank=0, world=0),
+                dict(height=8, rank=0, world=2, weights=[0, 0]), dict(height=8, rank=0, world=2, weights=[-1, 2])]:
+        with pytest.raises(kifs.KifsError):
+            kifs.shard_stripes(**bad)

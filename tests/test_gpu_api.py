@@ -65,6 +65,12 @@ def test_host_pitch_and_ragged_sizes(gs, kifs, oracle):
         rows = raw.reshape(h, pitch)
         assert (rows[:, :w * 4].reshape(h, w, 4) == want).all()
         assert (rows[:, w * 4:] == 0xAB).all()  # padding untouched
+    # a host destination too small for its pitch is refused before the library copies into it
+    gs.update_screen_data(kifs.ScreenData(16, 4))
+    with pytest.raises(ValueError):
+        gs.render(out=np.zeros(16 * 4 * 4, dtype=np.uint8), pitch_bytes=16 * 4 + 32)
+    with pytest.raises(ValueError):
+        gs.render(out=np.zeros(16 * 4 * 4, dtype=np.uint8), pitch_bytes=60)
 
 
 def test_bands_tile_the_frame(gs, kifs, oracle):
@@ -235,7 +241,7 @@ def test_tile_order_feedback_never_changes_pixels(gs, kifs, oracle):
 
 @pytest.mark.parametrize("scene", ["julia", "sierpinski", "bunny", "genjulia"])
 def test_batch_launch_equals_single_frames(scene, gs, kifs, oracle):
-    """kifs_render_batch_async: 1..8 frames per launch, one camera each, interleaved workgroups.
+    """kifs_render_batch_async: several frames per launch, one camera each, interleaved workgroups.
     Every frame must equal the same frame rendered alone (and the oracle's), for full frames and
     for a band that starts and ends inside a tile; the context's own camera is left alone."""
     import torch
@@ -277,11 +283,11 @@ def test_batch_launch_argument_checks(gs, kifs):
     gs.update_screen_data(kifs.ScreenData(64, 40))
     gs.update_options(kifs.GuiData())
     out = torch.zeros((40, 64, 4), dtype=torch.uint8, device="cuda:0")
-    cams = (CameraUniform * 9)(*[kifs.CameraData().into_buffer_data() for _ in range(9)])
-    ptrs = (C.c_void_p * 9)(*[out.data_ptr()] * 9)
+    cams = (CameraUniform * 33)(*[kifs.CameraData().into_buffer_data() for _ in range(33)])
+    ptrs = (C.c_void_p * 33)(*[out.data_ptr()] * 33)
     call = lambda n, cams_, ptrs_, pitch=256, y0=0, y1=40, enc=1: lib.kifs_render_batch_async(
         gs._ctx, None, n, cams_, ptrs_, pitch, y0, y1, enc)
-    assert call(0, cams, ptrs) == 7 and call(9, cams, ptrs) == 7 and call(-1, cams, ptrs) == 7  # BAD_ARG
+    assert call(0, cams, ptrs) == 7 and call(33, cams, ptrs) == 7 and call(-1, cams, ptrs) == 7  # BAD_ARG
     assert call(2, None, ptrs) == 7 and call(2, cams, None) == 7
     null_second = (C.c_void_p * 2)(out.data_ptr(), None)
     assert call(2, cams, null_second) == 7
@@ -290,7 +296,7 @@ def test_batch_launch_argument_checks(gs, kifs):
     assert call(2, cams, ptrs, pitch=100) == 3           # BAD_SIZE: pitch < 4 * width
     assert call(2, cams, ptrs, y0=5, y1=41) == 7 and call(2, cams, ptrs, enc=5) == 7
     assert call(2, cams, ptrs, y0=7, y1=7) == 0          # empty band: nothing to do
-    assert call(8, cams, ptrs) == 0
+    assert call(8, cams, ptrs) == 0 and call(32, cams, ptrs) == 0
     gs.synchronize()
 
 

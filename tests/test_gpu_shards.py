@@ -1,0 +1,208 @@
+"""Row shards on the GPU: kifs_shard_stripes / kifs_render_shard_async / kifs_unpack_shard_async,
+the building blocks of bench.py's N > 1 path, exercised on one device: the shards of all "ranks"
+rendered one after another must tile the frame exactly (packed + unpack, and in place)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import oracle_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(kifs, name):
+    FG, PS = kifs.FractalGroup, kifs.PrimitiveShape
+    return {
+        "julia": (kifs.GuiData(fractal_group=FG.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=96),
+                  (12, 10, 10), (330, 203)),
+        "sierpinski": (kifs.GuiData(primitive_shape=PS.SierpinskiTetrahedron, max_iterations=96),
+                       (100, 10, 12), (300, 170)),
+        "bunny": (kifs.GuiData(primitive_shape=PS.Bunny, max_iterations=64), (100, 10, 10), (100, 61)),
+        "heatmap": (kifs.GuiData(fractal_group=FG.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=64,
+                                 is_heatmap=True), (12, 10, 10), (160, 99)),
+    }[name]
+
+
+@pytest.mark.parametrize("scene", ["julia", "sierpinski", "bunny", "heatmap"])
+@pytest.mark.parametrize("world,weights", [(3, None), (8, None), (4, [3, 1, 1, 1])])
+def test_shards_tile_the_frame(scene, world, weights, gs, kifs, oracle):
+    import torch
+    gui, iters, (W, H) = _scene(kifs, scene)
+    screen = kifs.ScreenData(W, H)
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(*iters)
+    cams = [kifs.CameraData(origin_distance=3.0 + 0.3 * k, phi=0.7 * k, theta=0.2 * k - 0.3) for k in range(3)]
+    want = [oracle_frame(oracle, kifs, screen, c, gui, iters) for c in cams]
+    stream = torch.cuda.Stream()
+    n = len(cams)
+    frames_packed = torch.zeros((n, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    frames_inplace = torch.zeros((n, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    total = 0
+    for r in range(world):
+        stripes, rows = kifs.shard_stripes(H, r, world, weights)
+        total += rows
+        if not stripes:
+            continue
+        shard = torch.full((n, rows, W, 4), 0x5A, dtype=torch.uint8, device="cuda:0")
+        gs.render_shard_async([shard[i] for i in range(n)], cams, stripes, in_place=False, stream=stream)
+        gs.unpack_shard_async(frames_packed, shard, stripes, stream=stream)
+        gs.render_shard_async([frames_inplace[i] for i in range(n)], cams, stripes, in_place=True, stream=stream)
+        stream.synchronize()
+        # the packed shard itself: stripe k at rows [8k, 8k + 8)
+        got = shard.cpu().numpy()
+        y = 0
+        for s in stripes:
+            h = min(H, 8 * s + 8) - 8 * s
+            for i in range(n):
+                assert (got[i, y:y + h] == want[i][8 * s:8 * s + h]).all(), (scene, r, s, i)
+            y += h
+        assert y == rows
+    assert total == H
+    for i in range(n):
+        assert (frames_packed[i].cpu().numpy() == want[i]).all(), (scene, world, i, "packed + unpack")
+        assert (frames_inplace[i].cpu().numpy() == want[i]).all(), (scene, world, i, "in place")
+
+
+def test_headline_shards_take_the_requeuing_kernel(gs, kifs, oracle):
+    """1080p Julia, 8 orbit frames per launch, the 8 shards of an 8-GPU node rendered in turn on
+    this device (render_group_kernel: the launches are large enough for the throughput path):
+    gathered frames == frames rendered whole; one frame is checked against the oracle."""
+    import torch
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    W, H = w.screen.width, w.screen.height
+    gs.update_screen_data(w.screen)
+    gs.update_options(w.gui)
+    gs.set_iters(*w.iters)
+    cams = [orbit_camera(w, 5 * k) for k in range(8)]
+    stream = torch.cuda.Stream()
+    whole = torch.zeros((8, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    gs.render_batch_async([whole[i] for i in range(8)], cams, stream=stream)
+    gathered = torch.zeros_like(whole)
+    used_rounds = []
+    for r in range(8):
+        stripes, rows = kifs.shard_stripes(H, r, 8)
+        assert stripes == list(range(r, 135, 8))
+        if r == 0:
+            gs.render_shard_async([gathered[i] for i in range(8)], cams, stripes, in_place=True, stream=stream)
+        else:
+            shard = torch.zeros((8, rows, W, 4), dtype=torch.uint8, device="cuda:0")
+            gs.render_shard_async([shard[i] for i in range(8)], cams, stripes, stream=stream)
+            gs.unpack_shard_async(gathered, shard, stripes, stream=stream)
+        used_rounds.append(gs.debug_last_round_steps())
+    stream.synchronize()
+    assert all(u > 0 for u in used_rounds), used_rounds
+    assert torch.equal(gathered, whole)
+    want = oracle_frame(oracle, kifs, w.screen, cams[3], w.gui, w.iters)
+    assert (gathered[3].cpu().numpy() == want).all()
+
+
+def test_batch_of_32_frames(gs, kifs, oracle):
+    """KIFS_MAX_BATCH = 32 views in one launch (kernel argument of 2.1 KB)."""
+    import torch
+    assert kifs.MAX_BATCH == 32
+    gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=64)
+    screen = kifs.ScreenData(128, 72)
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(12, 10, 10)
+    cams = [kifs.CameraData(origin_distance=3.0 + 0.05 * k, phi=0.2 * k, theta=0.03 * k - 0.4) for k in range(32)]
+    outs = torch.zeros((32, 72, 128, 4), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    gs.render_batch_async([outs[i] for i in range(32)], cams, stream=stream)
+    stream.synchronize()
+    got = outs.cpu().numpy()
+    for k in (0, 7, 8, 19, 31):
+        assert (got[k] == oracle_frame(oracle, kifs, screen, cams[k], gui, (12, 10, 10))).all(), k
+    assert len({got[k].tobytes() for k in range(32)}) == 32
+    with pytest.raises(ValueError):
+        gs.render_batch_async([outs[0]] * 33, cams + cams[:1], stream=stream)
+
+
+def test_shard_argument_checks(gs, kifs):
+    import torch
+    from kifs_raymarching_amd._lib import CameraUniform, lib
+    gs.update_screen_data(kifs.ScreenData(64, 40))  # 5 stripes
+    gs.update_options(kifs.GuiData())
+    out = torch.zeros((2, 40, 64, 4), dtype=torch.uint8, device="cuda:0")
+    cams = (CameraUniform * 2)(*[kifs.CameraData().into_buffer_data() for _ in range(2)])
+    ptrs = (C.c_void_p * 2)(out[0].data_ptr(), out[1].data_ptr())
+    arr = lambda *s: (C.c_int * len(s))(*s)
+
+    def call(st, n=None, count=2, cams_=cams, ptrs_=ptrs, pitch=256, in_place=1, enc=1):
+        return lib.kifs_render_shard_async(gs._ctx, None, count, cams_, ptrs_, pitch, st,
+                                           len(st) if n is None else n, in_place, enc)
+    assert call(arr(0, 2, 4)) == 0
+    assert call(arr(0, 2, 4), n=0) == 0           # an empty shard renders nothing
+    assert call(arr(2, 0)) == 7                   # not ascending
+    assert call(arr(1, 1)) == 7                   # repeated
+    assert call(arr(0, 5)) == 7                   # stripe 5 starts at row 40 = H
+    assert call(arr(-1)) == 7
+    assert lib.kifs_render_shard_async(gs._ctx, None, 2, cams, ptrs, 256, None, 1, 1, 1) == 7  # NULL list
+    assert call(arr(0), cams_=None) == 7          # no cameras for two frames
+    assert call(arr(0), count=1, cams_=None) == 0  # one frame: the context's camera
+    assert call(arr(0), count=33) == 7
+    assert call(arr(0), pitch=100) == 3
+    assert call(arr(0), enc=9) == 7
+    un = lambda st, fp=256, sp=256: lib.kifs_unpack_shard_async(gs._ctx, None, 2, out.data_ptr(), fp, 40 * 256,
+                                                                 out.data_ptr(), sp, 8 * 256, st, len(st))
+    assert un(arr(4, 2)) == 7 and un(arr(0), fp=100) == 3 and un(arr(0), sp=254) == 3
+    gs.synchronize()
+
+
+def test_shardframes_on_gpu_world1(gs, kifs, oracle):
+    """ShardFrames with one rank: the root renders every stripe in place, no exchange."""
+    import torch
+    from kifs_raymarching_amd.bands import ShardFrames
+    screen = kifs.ScreenData(96, 54)
+    gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2))
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(12, 10, 10)
+    cams = [kifs.CameraData(phi=0.1 * k) for k in range(6)]
+    sf = ShardFrames(96, 54, 0, 1, "cuda:0", frames_per_step=2)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for k in range(3):
+            sf.step(k, lambda outs, first, stripes, in_place: gs.render_shard_async(
+                outs, cams[first:first + 2], stripes, in_place=in_place, stream=s))
+        sf.wait_all()
+    s.synchronize()
+    for i in range(2):
+        want = oracle_frame(oracle, kifs, screen, cams[4 + i], gui, (12, 10, 10))
+        assert (sf.frames(2)[i].cpu().numpy() == want).all()
+
+
+def test_feedback_survives_a_change_of_pipeline(gs, kifs, oracle):
+    """Tile-order feedback is on for 1080p Julia frames and off for the bunny: switching options
+    Julia -> bunny -> Julia between launches (with a sort possibly still running on the side
+    stream) must not lose or duplicate a tile."""
+    import torch
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    bunny = WORKLOADS["n2_bunny_1080p"]
+    W, H = w.screen.width, w.screen.height
+    gs.update_screen_data(w.screen)
+    gs.set_iters(*w.iters)
+    cam = orbit_camera(w, 11)
+    gs.set_camera(cam)
+    want = oracle_frame(oracle, kifs, w.screen, cam, w.gui, w.iters)
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+    band = torch.zeros((16, W, 4), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    for cycle in range(6):
+        gs.update_options(w.gui)
+        for _ in range(2 + cycle % 3):  # stop the feedback period at every phase
+            gs.render_async(out, stream=stream)
+        gs.update_options(bunny.gui)
+        gs.render_async(band, stream=stream, y0=536, y1=552)  # the table of another geometry
+        gs.render_async(out[:8], stream=stream, y0=0, y1=8) if cycle % 2 else None
+        gs.update_options(w.gui)
+        out.zero_()
+        gs.render_async(out, stream=stream)
+        stream.synchronize()
+        assert (out.cpu().numpy() == want).all(), cycle
+    order = gs.debug_get_tile_order()
+    assert len({int(o) for o in order}) == 60 * 135

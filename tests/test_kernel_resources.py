@@ -1,0 +1,70 @@
+"""Resource ceilings of every gfx950 kernel, from hipcc's own report (`make -C csrc report`):
+no scratch, no spills, VGPR budgets per pipeline.  The hand-written loops pin physical registers
+(v30-v63, s74-s97: kifs_scene.hpp, kifs_julia_march_asm.hpp); after a toolchain bump or an edit
+this is the test that notices a spill or a lost occupancy step.  CPU only (hipcc cross-compiles)."""
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+CSRC = Path(__file__).resolve().parent.parent / "kifs_raymarching_amd" / "csrc"
+
+
+@pytest.fixture(scope="module")
+def report():
+    p = subprocess.run(["make", "-C", str(CSRC), "report"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in (p.stdout + p.stderr).splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\S+) \[-Rpass", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = m.group(2)
+    names = subprocess.run(["c++filt"] + list(kernels), capture_output=True, text=True).stdout.split("\n")
+    return {n.strip(): v for n, v in zip(names, kernels.values())}
+
+
+def _budget(name):
+    """(max VGPRs, min waves per SIMD) for a kernel by its demangled name."""
+    m = re.search(r"render(?:_group)?_kernel<(\d+), (\d+)(?:, (\d+))?>", name)
+    if "bunny_quad" in name or (m and m.group(1) == "0" and m.group(2) == "5"):
+        return 224, 2                      # the bunny keeps 156 weights per lane in registers
+    if m:
+        group, tiles = int(m.group(1)), int(m.group(3) or 0)
+        vgprs = 80 if group in (1, 2) else 64   # Julia / gen-Julia: v30-v63 pinned + compiler's; KIFS: <= 64
+        return vgprs, (5 if tiles == 2 else 6)  # two tiles per workgroup: 27 KB of LDS -> 5 workgroups per CU
+    return 64, 8                           # tile order, unpack, point and math evaluation
+
+
+def test_every_kernel_is_reported(report):
+    have = " ".join(report)
+    for needle in ["render_kernel<1, 0>", "render_kernel<1, 1>", "render_kernel<2, 0>", "render_kernel<0, 4>",
+                   "render_group_kernel<1, 1, 2>", "render_group_kernel<0, 4, 2>", "render_group_kernel<0, 5, 1>",
+                   "render_bunny_quad_kernel", "tile_order_kernel", "unpack_stripes_kernel"]:
+        assert needle in have, needle
+    assert len(report) >= 40
+
+
+def test_no_scratch_no_spills_and_register_budgets(report):
+    bad = []
+    for name, r in report.items():
+        vmax, occ_min = _budget(name)
+        if int(r["ScratchSize [bytes/lane]"]) != 0 or int(r["VGPRs Spill"]) != 0:
+            bad.append((name, "scratch/spill", r))
+        # SGPR "spills" live in lanes of a VGPR (v_writelane / v_readlane), never in memory.  The frame
+        # constants alone are ~70 SGPRs and the hand-written loops pin s74-s97, so the Julia kernels park
+        # some constants that way outside their loops (21-44 today); everything else must not spill.
+        sgpr_max = 48 if re.search(r"render(_group)?_kernel<[12], ", name) else 4 if "render" in name else 0
+        if int(r["SGPRs Spill"]) > sgpr_max:
+            bad.append((name, f"SGPR spills {r['SGPRs Spill']} > {sgpr_max}", r))
+        if r.get("Dynamic Stack") != "False":
+            bad.append((name, "dynamic stack", r))
+        if int(r["VGPRs"]) > vmax or int(r["AGPRs"]) != 0:
+            bad.append((name, f"VGPRs {r['VGPRs']} > {vmax}", r))
+        if int(r["Occupancy [waves/SIMD]"]) < occ_min:
+            bad.append((name, f"occupancy {r['Occupancy [waves/SIMD]']} < {occ_min}", r))
+    assert not bad, [b[:2] for b in bad]
