@@ -4,14 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 A "step" is one pass of the render path over one batch of synthetic input: the next
-`--frames-per-launch` (default 8) frames of the workload's ORBIT -- one camera pose and one
+`--frames-per-launch` (default 32) frames of the workload's ORBIT -- one camera pose and one
 destination per frame, packed by the host camera model exactly as the reference does per frame
 (render.rs:320-345) -- rendered by one kifs_render_batch_async launch.  The default workload is
 BASELINE.json's metric configuration: 1920x1080 quaternion-Julia, 256 march steps, 12 SDF
 iterations.  Rank 0 prints ONE JSON line; besides the headline it carries, measured in the same
-process after the timed region, `secondary.lone_frame` (one frame per launch: the latency path)
-and `secondary.fixed_camera` (the same view in every slot of the batch: the most favourable case
-for the tile-order feedback).
+process after the timed region, `secondary.lone_frame` (one frame per launch: the latency path),
+`secondary.orbit_x8` (8 frames per launch) and `secondary.fixed_camera` (the same view in all 8 slots
+of a batch: round 1's headline, the most favourable case for the tile-order feedback).
 
 N > 1 (one process per GPU; `python bench.py --gpus N` launches the N ranks itself, or it runs
 under torch.distributed.run): the north star's path.  Every frame is split into ROW SHARDS --
@@ -52,8 +52,8 @@ METRIC = "Mpixels/s at 1920x1080, 256 march steps, 12 SDF iters; %HBM-peak"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default=None, help="name in kifs_raymarching_amd.configs.WORKLOADS")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall-clock budget of the cpu_baseline sample (0 disables it)")
@@ -62,8 +62,8 @@ def parse():
                     help="orbit (default): a distinct pose per frame, phi = 2*pi*frame/120 (host camera model + "
                          "64-byte uniform per frame); fixed: every frame is the workload's view")
     ap.add_argument("--orbit", action="store_true", help="same as --camera orbit (kept for older scripts)")
-    ap.add_argument("--frames-per-launch", type=int, default=8,
-                    help="frames of the sequence per launch (1..32); 1 = the lone-frame latency path")
+    ap.add_argument("--frames-per-launch", type=int, default=32,
+                    help="frames of the sequence per launch (1..32, default 32); 1 = the lone-frame latency path")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N = 1 only: launches kept in flight on separate contexts and streams")
     ap.add_argument("--shard", default="stripes", choices=["stripes", "bands", "frames"],
@@ -71,9 +71,12 @@ def parse():
                          "contiguous row bands gathered to rank 0, or whole frames per rank")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1, row shards: frames per step = N x frames-per-launch (weak) or frames-per-launch")
-    ap.add_argument("--root-weight", type=int, default=1,
-                    help="N > 1, stripes: rank 0 renders this many stripes for every one of a peer "
-                         "(the root's xGMI ingest is the bottleneck of a gather)")
+    ap.add_argument("--root-weight", default="auto",
+                    help="N > 1, stripes: rank 0 renders this many stripes for every one of a peer.  Every peer's "
+                         "pixels reach rank 0 over ONE point-to-point xGMI link, far slower than a GPU renders "
+                         "them; 'auto' (default) times one step's rendering and one step's gather with equal "
+                         "shares during warm-up and gives rank 0 the share at which its rendering takes as long "
+                         "as the peers' transfers; an integer fixes the weight (1 = equal shares)")
     ap.add_argument("--deliver", default="none", choices=["none", "root"],
                     help="N > 1, --shard frames: leave frames where they were rendered, or send them to rank 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -304,7 +307,7 @@ def main():
                 "kernel_ms": sum(r[0] * r[1] for r in reads) / max(n, 1),
                 "kernel_ms_min": min((r[2] for r in reads if r[0] > 0), default=0.0),
                 "kernel_ms_max": max((r[3] for r in reads if r[0] > 0), default=0.0),
-                "round_steps": gss[0].debug_last_round_steps()}
+                "round_steps": gss[0].debug_last_round_steps(), "group_tiles": gss[0].debug_last_group_tiles()}
 
     def whole_frames(frames_per_launch, camera_mode, deliver=False):
         """Every rank renders whole frames: step k, rank r: frames (k N + r) b .. + b - 1 (at N = 1
@@ -330,12 +333,12 @@ def main():
                 fs.step(k, render)
         return fs, step
 
-    def row_shards(frames_per_step, camera_mode, contiguous):
+    def row_shards(frames_per_step, camera_mode, contiguous, root_weight=1):
         """The north star's path: every rank renders its row shard of the step's frames (launches of
         at most MAX_BATCH frames) and rank 0 gathers them."""
         weights = None
-        if not contiguous and args.root_weight != 1:
-            weights = [args.root_weight] + [1] * (world - 1)
+        if not contiguous and root_weight != 1:
+            weights = [root_weight] + [1] * (world - 1)
         sf = ShardFrames(W, H, rank, world, device, frames_per_step=frames_per_step, buffers=2,
                          weights=weights, contiguous=contiguous,
                          unpack=lambda frames, shards, stripes: gs.unpack_shard_async(
@@ -350,13 +353,58 @@ def main():
         def step(k):
             with torch.cuda.stream(streams[0]):
                 sf.step(k, render)
+        sf.render = render
         return sf, step
+
+    def calibrate_root_weight(frames_per_step):
+        """Equal shares first: time rank 0's rendering of one step and, separately, one step's gather
+        (all peers sending at once, each over its own link, plus the unpack).  With rank 0 at weight w
+        its rendering scales by w N / (w + N - 1) and every transfer by N / (w + N - 1): they take
+        equally long at w = t_gather / t_render.  Rank 0 decides, everybody follows."""
+        sf, step = row_shards(frames_per_step, args.camera, contiguous=False)
+        t_render = t_gather = 0.0
+        with torch.cuda.stream(streams[0]):
+            for k in range(2):
+                step(k)
+            sf.wait_all()
+            torch.cuda.synchronize()
+            for k in range(2, 5):
+                barrier()
+                t0 = time.perf_counter()
+                outs, in_place = sf.targets(k)
+                if sf.rows[rank] > 0:
+                    sf.render(outs, k * frames_per_step, sf.my_stripes, in_place)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                barrier()
+                t2 = time.perf_counter()
+                sf.gather_async(k)
+                sf.wait(k)
+                torch.cuda.synchronize()
+                barrier()
+                t3 = time.perf_counter()
+                if k > 2:  # the first timed pass still warms things up
+                    t_render += (t1 - t0) / 2
+                    t_gather += (t3 - t2) / 2
+        w = max(1, min(16, int(round(t_gather / max(t_render, 1e-9))))) if rank == 0 else 0
+        t = torch.tensor([w], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
+        dist.broadcast(t, src=0)
+        del sf
+        return int(t.item()), {"render_ms_equal_shares": round(t_render * 1e3, 4),
+                               "gather_ms_equal_shares": round(t_gather * 1e3, 4)}
 
     # ---- the headline sequence
     sharded = world > 1 and args.shard in ("stripes", "bands")
+    root_weight, calibration = 1, None
     if sharded:
         frames_per_step = B * world if args.scaling == "weak" else B
-        pipe, step = row_shards(frames_per_step, args.camera, contiguous=(args.shard == "bands"))
+        if args.shard == "stripes":
+            if args.root_weight == "auto":
+                root_weight, calibration = calibrate_root_weight(frames_per_step)
+            else:
+                root_weight = max(1, int(args.root_weight))
+        pipe, step = row_shards(frames_per_step, args.camera, contiguous=(args.shard == "bands"),
+                                root_weight=root_weight)
         rows0 = pipe.rows[rank]
         frames_per_launch = min(frames_per_step, K.MAX_BATCH)
         launches_per_step = -(-frames_per_step // K.MAX_BATCH)
@@ -407,6 +455,11 @@ def main():
                 secondary["lone_frame"] = summarise(
                     run(p2, s2, sec_steps, sec_warm), 1, sec_steps,
                     "one frame per launch, a new orbit pose and a 64-byte camera upload per frame: the latency path")
+            if B != 8:
+                p5, s5 = whole_frames(8, "orbit")
+                secondary["orbit_x8"] = summarise(
+                    run(p5, s5, sec_steps, sec_warm), 8, sec_steps,
+                    "8 orbit frames per launch: a quarter of the default batch, a quarter of its latency")
             if not (B == 8 and args.camera == "fixed"):
                 p3, s3 = whole_frames(8, "fixed")
                 secondary["fixed_camera"] = summarise(
@@ -443,7 +496,8 @@ def main():
     if rank == 0:
         mpix = frames_per_step * W * H * args.steps / elapsed / 1e6
         bunny = int(w.gui.fractal_group) == 0 and int(w.gui.primitive_shape) == 5
-        kernel_name = ("render_group_kernel" if m["round_steps"] > 0 else
+        kernel_name = ("render_wave_kernel" if m["round_steps"] > 0 and m["group_tiles"] == 0 else
+                       "render_group_kernel" if m["round_steps"] > 0 else
                        "render_bunny_quad_kernel" if bunny else "render_kernel")
         # average duration of the dominant kernel over the timed region (per-launch event pairs);
         # ms_per_step additionally contains the inter-launch gaps and, at N > 1, the exchange
@@ -458,7 +512,7 @@ def main():
             parallelism = (f"{world} GPUs, one process each: row shards ("
                            + ("contiguous bands of 8-row stripes" if args.shard == "bands" else
                               "8-row stripes dealt round-robin"
-                              + (f", rank 0 weighted x{args.root_weight}" if args.root_weight != 1 else ""))
+                              + (f", rank 0 weighted x{root_weight}" if root_weight != 1 else ""))
                            + f") of {frames_per_step} frames per step, gathered into rank 0's frames by grouped "
                            "RCCL point-to-point over xGMI + stripe unpack")
         else:
@@ -496,6 +550,11 @@ def main():
             "per_rank_kernel_ms": [round(x, 5) for x in per_rank_kernel_ms],
             "per_rank_step_ms": [round(x, 5) for x in per_rank_step_ms],
         }
+        if sharded:
+            out["config"]["root_weight"] = root_weight
+            out["config"]["rows_per_rank"] = pipe.rows
+            if calibration:
+                out["config"]["root_weight_calibration"] = calibration
         if secondary:
             out["secondary"] = secondary
         if check is not None:

@@ -290,6 +290,10 @@ int kifs_debug_counters(kifs_ctx* ctx, int enable, unsigned long long out[8]);
 /* Round length (march steps) of the ray re-queuing used by the context's latest launch; 0 = that
  * launch marched one wave per 8x8 block.  For tests. */
 int kifs_debug_last_round_steps(kifs_ctx* ctx);
+/* Shape of the throughput path in the context's latest launch: 0 = one single-wave workgroup per
+ * tile (render_wave_kernel), 1 or 2 = tiles per 256-thread workgroup (render_group_kernel), -1 = the
+ * launch did not re-queue rays at all.  For tests and bench.py's kernel name. */
+int kifs_debug_last_group_tiles(kifs_ctx* ctx);
 /* Tuning hooks: read / replace the order in which workgroups take the tiles of the full
  * frame (a permutation of (tile_x | tile_y << 16)); the order only affects speed. */
 int kifs_debug_get_tile_order(kifs_ctx* ctx, uint32_t* order, size_t max_count, size_t* count);

@@ -53,6 +53,7 @@ struct TileTable {
     bool sort_pending = false;        // d_order_alt holds (or will hold) a fresh order
     bool feedback = true;             // reorder from costs (off once the caller pins an order)
     uint32_t count = 0;
+    uint32_t cost_shift = 0;          // scale of the costs the latest recording launch wrote (see record_costs)
     uint64_t last_use = 0;
 };
 constexpr int MAX_TILE_TABLES = 8;
@@ -76,6 +77,7 @@ struct kifs_ctx {
     KifsExtensions ext{};  // all zero: the reference's behaviour
     int frames_in_flight = 1;  // kifs_set_frames_in_flight
     int last_round_steps = 0;  // kifs_debug_last_round_steps
+    int last_group_tiles = -1; // kifs_debug_last_group_tiles
     float h_srgb[256] = {};    // host copy of the sRGB threshold table (d_srgb)
     // per-launch profiling ring (kifs_set_profiling)
     bool profiling = false;
@@ -90,6 +92,19 @@ struct kifs_ctx {
 };
 
 namespace {
+
+// Tuning overrides (KIFS_ROUND_STEPS, KIFS_GROUP_TILES, KIFS_TILE_FEEDBACK, KIFS_FEEDBACK_PERIOD,
+// KIFS_BATCH_PERIOD; KIFS_LDS_PAD in kifs_kernels.hip) are honoured only when KIFS_TUNING=1 is set as
+// well: they exist for tools/sweep_kernels.sh and friends, not for production hosts.  -1 = not set.
+int tuning_knob(const char* name) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("KIFS_TUNING");
+        return e && e[0] == '1';
+    }();
+    if (!enabled) return -1;
+    const char* e = std::getenv(name);
+    return e ? int(std::strtol(e, nullptr, 10)) : -1;
+}
 
 // KIFS_DEBUG=1 prints the failing HIP call to stderr (status codes stay the contract).
 bool hip_ok(hipError_t e, const char* what) {
@@ -217,10 +232,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
         // Not for heatmap frames (their per-ray step count is kept by the one-wave-per-block
         // march), not with a non-positive epsilon (the queue rebuilds p from t and relies on
         // t > 0 after a step), not for marches too short to repay the rounds' barriers.
-        static const int forced = [] {
-            const char* e = std::getenv("KIFS_ROUND_STEPS");
-            return e ? int(std::strtol(e, nullptr, 10)) : -1;
-        }();
+        static const int forced = tuning_knob("KIFS_ROUND_STEPS");
         int rounds = forced >= 0 ? forced : (o.fractal_group_id == uint32_t(kifs::GROUP_JULIA) ? 16 : 8);
         if (o.is_heatmap || !(o.epsilon > 0.0f) || o.max_iterations < 2 * rounds) rounds = 0;
         P->round_steps = rounds;
@@ -267,11 +279,11 @@ static void free_table(TileTable& t) {
     t = TileTable();
 }
 
-// KIFS_TILE_FEEDBACK: 0 = never, 1 (default) = per pipeline thresholds, 2 = every frame of 2048+ tiles.
+// KIFS_TILE_FEEDBACK (tuning): 0 = never, 1 (default) = per pipeline thresholds, 2 = every frame of 2048+ tiles.
 static int tile_feedback_mode() {
     static const int mode = [] {
-        const char* e = std::getenv("KIFS_TILE_FEEDBACK");
-        return e ? int(std::strtol(e, nullptr, 10)) : 1;
+        const int v = tuning_knob("KIFS_TILE_FEEDBACK");
+        return v >= 0 ? v : 1;
     }();
     return mode;
 }
@@ -361,6 +373,30 @@ TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1, const 
     return slot;
 }
 
+// How many of a launch's tiles (per view) can contain rays with real work: those the projected
+// bounding sphere of the scene covers (fill_params: every estimate obeys d(p) >= |p| - B, so a ray that
+// passes the origin at more than R = B + epsilon never hits).  pi r_px^2 / 256 with
+// r_px = H/2 * R / sqrt(d^2 - R^2) (focal length 1, uv.y in [-1, 1]), scaled by the launch's share of the
+// frame's rows; every tile when the camera is inside the sphere or the culls are off.  This is the
+// quantity the launch-shape rules below are written in: it follows the camera distance and the frame
+// size together, where tile counts and pixel counts do not.
+double disc_tiles(const kifs::FrameParams& P, int frame_height, uint32_t tile_count) {
+    if (P.cull_n2 <= 0.0f || P.is_heatmap) return double(tile_count);
+    const double R2 = double(P.cull_n2) / 1.1;  // (B + epsilon)^2
+    const double d2 = double(P.origin.x) * P.origin.x + double(P.origin.y) * P.origin.y +
+                      double(P.origin.z) * P.origin.z;
+    const double frame_px = double(P.width) * double(frame_height);
+    double disk_px = frame_px;  // camera inside the sphere: everything is a candidate
+    if (d2 > R2 * 1.0001) {
+        const double r_uv = std::sqrt(R2 / (d2 - R2));          // tangent of the sphere's angular radius
+        const double r_px = r_uv * 0.5 * double(frame_height);
+        disk_px = std::min(frame_px, 3.14159265358979 * r_px * r_px);
+    }
+    // a band or shard of a frame gets its share of the disk
+    const double share = frame_px > 0 ? double(tile_count) * (kifs::TILE_W * kifs::TILE_H) / frame_px : 1.0;
+    return std::min(double(tile_count), disk_px * std::min(1.0, share) / (kifs::TILE_W * kifs::TILE_H));
+}
+
 // Residency rule for the Julia pipelines.  The long rays of a frame slow each other down as soon
 // as they share a SIMD (~1490 cycles per march step alone, ~1570 with one neighbour, ~1900 with
 // seven), and after the bounding-sphere culls nothing else needs the slots: the only tiles
@@ -369,23 +405,10 @@ TileTable* tile_table(kifs_ctx* c, int width, int height, int y0, int y1, const 
 // near its lone-wave speed (1080p, camera at distance 5: 207 -> 172 us at one workgroup per
 // CU); if they are many (4096^2, or a camera close to the fractal) the frame needs every slot for
 // its long-marching waves and full residency wins (4096^2: 0.70 ms vs 1.95 ms capped).
-int residency_for(const kifs::FrameParams& P, uint32_t group, int frame_height, uint32_t tile_count) {
+int residency_for(const kifs::FrameParams& P, uint32_t group, double heavy_tiles) {
     if (group != kifs::GROUP_JULIA || P.cull_n2 <= 0.0f || P.is_heatmap) return 0;
-    const double R2 = double(P.cull_n2) / 1.1;  // (2 + epsilon)^2
-    const double d2 = double(P.origin.x) * P.origin.x + double(P.origin.y) * P.origin.y +
-                      double(P.origin.z) * P.origin.z;
-    const double frame_px = double(P.width) * double(frame_height);
-    double disk_px = frame_px;  // camera inside the sphere: everything is a candidate
-    if (d2 > R2 * 1.0001) {
-        const double r_uv = std::sqrt(R2 / (d2 - R2));          // tangent of the sphere's angular radius
-        const double r_px = r_uv * 0.5 * double(frame_height);  // focal length 1, uv.y in [-1, 1]
-        disk_px = std::min(frame_px, 3.14159265358979 * r_px * r_px);
-    }
-    // a band of a frame gets its share of the disk
-    const double band_share = frame_px > 0 ? double(tile_count) * (kifs::TILE_W * kifs::TILE_H) / frame_px : 1.0;
-    const double disk_tiles = disk_px * std::min(1.0, band_share) / (kifs::TILE_W * kifs::TILE_H);
-    if (disk_tiles <= 1024.0) return 1;
-    if (disk_tiles <= 2048.0) return 2;
+    if (heavy_tiles <= 1024.0) return 1;
+    if (heavy_tiles <= 2048.0) return 2;
     return 0;
 }
 
@@ -478,9 +501,8 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     //   k == 0: record costs, event;   k == 1: sort the costs of launch 0 on the side stream;
     //   k == 2: adopt the new order (wait for the sort);   otherwise: a plain launch.
     static const uint64_t FEEDBACK_PERIOD = [] {
-        const char* e = std::getenv("KIFS_FEEDBACK_PERIOD");
-        long v = e ? std::strtol(e, nullptr, 10) : 4;
-        return uint64_t(v < 3 ? 3 : v);
+        const int v = tuning_knob("KIFS_FEEDBACK_PERIOD");
+        return uint64_t(v < 0 ? 4 : v < 3 ? 3 : v);
     }();
     if (use_feedback && tt->last_stream && tt->last_stream != stream) {
         // The caller moved to another stream: order this stream after the launches of the old
@@ -494,9 +516,8 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     // launches are long and its views move: an orbit; measured best for fixed and moving cameras;
     // KIFS_BATCH_PERIOD overrides)
     static const uint64_t BATCH_PERIOD = [] {
-        const char* e = std::getenv("KIFS_BATCH_PERIOD");
-        long v = e ? std::strtol(e, nullptr, 10) : 3;
-        return uint64_t(v < 2 ? 2 : v);
+        const int v = tuning_knob("KIFS_BATCH_PERIOD");
+        return uint64_t(v < 0 ? 3 : v < 2 ? 2 : v);
     }();
     const uint64_t period = count > 1 ? BATCH_PERIOD : FEEDBACK_PERIOD;
     const uint64_t k = use_feedback ? tt->launches % period : 0;
@@ -517,7 +538,7 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     }
     if (use_feedback && inline_sort && k == 1) {
         const uint32_t tiles_x = uint32_t((P.width + kifs::TILE_W - 1) / kifs::TILE_W);
-        if (!hip_ok(kifs::launch_tile_order(tt->d_cost[0], tt->d_order_alt, tt->count, tiles_x, stream),
+        if (!hip_ok(kifs::launch_tile_order(tt->d_cost[0], tt->d_order_alt, tt->count, tiles_x, tt->cost_shift, stream),
                     "tile_order_kernel launch"))
             return KIFS_ERR_RUNTIME;
         std::swap(tt->d_order, tt->d_order_alt);  // stream order: the sort precedes this launch
@@ -532,43 +553,66 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     P.tile_count = tt->count;
     P.tile_cost = record_costs ? tt->d_cost[0] : nullptr;
     if (P.counters) P.round_steps = 0;  // the per-wave diagnostics belong to the one-wave-per-block march
+    // ---- launch shape.  Everything below is decided from `load`: the launch's tiles that can hold rays
+    // with real work (the projected bounding sphere's tiles, all views), tools/cliff_sweep.py's x axis.
+    const uint32_t group_id = c->options.fractal_group_id;
+    const bool lone = count == 1 && c->frames_in_flight <= 1;
+    const bool bunny_scene = group_id == uint32_t(kifs::GROUP_KIFS) && c->options.primitive_id == uint32_t(kifs::PRIM_BUNNY);
+    const double heavy_tiles = disc_tiles(P, h, tt->count);
+    const double load = heavy_tiles * double(count);
     // the residency cap serves a lone frame's latency; concurrent frames want every slot
-    P.workgroups_per_cu = (c->frames_in_flight > 1 || count > 1)
-                              ? 0 : residency_for(P, c->options.fractal_group_id, h, tt->count);
+    P.workgroups_per_cu = lone ? residency_for(P, group_id, heavy_tiles) : 0;
     // a residency-capped launch is a lone frame bound by its longest rays: re-queuing helps
     // throughput, not that (1080p Julia: 0.143 ms without, 0.146 ms with)
     if (P.workgroups_per_cu >= 1) P.round_steps = 0;
     // (an uncapped lone Julia frame -- 4096^2 -- prefers longer rounds: 0.430 ms at 32 steps, 0.445 at 16)
-    if (P.round_steps == 16 && count == 1 && c->options.fractal_group_id == uint32_t(kifs::GROUP_JULIA) &&
-        P.max_iterations >= 64 && std::getenv("KIFS_ROUND_STEPS") == nullptr)
+    if (P.round_steps == 16 && count == 1 && group_id == uint32_t(kifs::GROUP_JULIA) && P.max_iterations >= 64 &&
+        tuning_knob("KIFS_ROUND_STEPS") < 0)
         P.round_steps = 32;
     // (nor does the lone bunny frame: 0.461 ms with the quad kernel, 0.670 ms in rounds)
-    const bool bunny_scene = c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS) &&
-                             c->options.primitive_id == uint32_t(kifs::PRIM_BUNNY);
     if (bunny_scene && count == 1) P.round_steps = 0;
     // nor does a launch too small to fill the device twice over (256x256 x 8 views = 2048
     // workgroups: 0.038 ms without, 0.062 ms with)
     if (uint64_t(tt->count) * uint64_t(count) < 4096u) P.round_steps = 0;
-    {   // Tiles per workgroup on the re-queuing path.  One tile's queue is short for most of its life
-        // (1080p Julia: mean 100 rays, four rounds in ten with <= 16), two neighbours of the cost order
-        // fill each other's waves: batched 1080p Julia 0.319 -> 0.281 ms, Sierpinski +4 %.  A lone
-        // frame loses instead (4096^2: 0.441 -> 0.465 ms): its heaviest workgroup sets the frame time
-        // and now has twice the rays; 8K KIFS frames have tiles enough to gain (+3 %).  Four tiles per
-        // workgroup need 54 KB of LDS and lose everywhere.  KIFS_GROUP_TILES overrides.
-        static const int forced = [] {
-            const char* e = std::getenv("KIFS_GROUP_TILES");
-            return e ? int(std::strtol(e, nullptr, 10)) : 0;
-        }();
-        const bool kifs_big = c->options.fractal_group_id == uint32_t(kifs::GROUP_KIFS) && tt->count >= 65536u;
-        // (the generalised Julia's few, very long workgroups lose 7 % when paired)
-        const bool genjulia = c->options.fractal_group_id == uint32_t(kifs::GROUP_GENJULIA);
-        // (nor the bunny: its 216 VGPRs allow two workgroups per CU either way, pairs just run longer)
-        P.group_tiles = forced > 0 ? forced : ((((count > 1 && !genjulia) || kifs_big) && !bunny_scene) ? 2 : 1);
+    {   // Shape of the re-queuing path (profiles/r02/sweep_shapes.jsonl: 5 frame sizes x 4 camera
+        // distances x 2 scenes x batches of 1 / 8 / 32, every shape forced in turn):
+        //   one WAVE per tile (render_wave_kernel) once the launch has several times more heavy tiles
+        //     than the device has workgroup slots -- then slots, not critical paths, set its duration, and
+        //     single-wave workgroups give four times as many (1080p Julia x32: 1.13 -> 0.88 ms; 4096^2 x8
+        //     +27 %; 8K Sierpinski x4 +16 %) -- from a load of 16 000 tiles for the Julia pipeline, 32 000
+        //     for the others, 30 000 for a lone frame (all its heavy tiles are one view's);
+        //   otherwise 256-thread workgroups (render_group_kernel), whose four waves take a tile's first,
+        //     crowded rounds side by side (a lone wave needs +30 % for the same tile): TWO tiles of the cost
+        //     order per workgroup when the launch is a batch with enough heavy tiles to pair (one tile's
+        //     queue is short for most of its life, neighbours of the cost order fill each other's waves:
+        //     batched 1080p Julia 0.319 -> 0.281 ms; below 3 500 heavy tiles pairing only halves the
+        //     workgroups that can run side by side: 720p x8 at distance 5, 0.222 -> 0.188 ms with one) or a
+        //     big lone KIFS frame (1440p Sierpinski at distance 2: -11 %), else ONE.
+        // Not the bunny (four lanes per ray, 216 VGPRs: pairs just run longer) and not the generalised
+        // Julia below the wave kernel's range (its few, very long workgroups lose 7 % when paired).
+        static const int forced = tuning_knob("KIFS_GROUP_TILES");
+        const bool julia = group_id == uint32_t(kifs::GROUP_JULIA);
+        const bool genjulia = group_id == uint32_t(kifs::GROUP_GENJULIA);
+        const bool kifs_scene = group_id == uint32_t(kifs::GROUP_KIFS);
+        const double wave_from = lone ? 30000.0 : (julia ? 16000.0 : 32000.0);
+        int shape = 1;
+        if (load >= wave_from) shape = 0;
+        else if (!lone && !genjulia && load >= 3500.0) shape = 2;
+        else if (lone && kifs_scene && load >= 12000.0) shape = 2;
+        if (forced >= 0) shape = forced;
+        if (bunny_scene) shape = 1;
+        P.group_tiles = shape;
     }
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
     const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
     if (timed && !hip_ok(hipEventRecord(c->prof_a[pslot], stream), "record(profile start)")) return KIFS_ERR_RUNTIME;
+    if (record_costs) {
+        // render_kernel / render_group_kernel record run times in units of 1024 cycles; the stream kernel
+        // sums the march steps of a tile's long rays over the batch's views: scale to the sort's 1024 bins
+        tt->cost_shift = 0;
+    }
     c->last_round_steps = P.round_steps;
+    c->last_group_tiles = P.round_steps > 0 ? P.group_tiles : -1;
     hipError_t e = kifs::launch_render(B, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
     if (!hip_ok(e, "render_kernel launch")) return KIFS_ERR_RUNTIME;
@@ -594,7 +638,7 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
             return KIFS_ERR_RUNTIME;
         const uint32_t tiles_x = uint32_t((P.width + kifs::TILE_W - 1) / kifs::TILE_W);
         if (!hip_ok(hipStreamWaitEvent(c->side_stream, tt->rendered[0], 0), "wait(render 0)") ||
-            !hip_ok(kifs::launch_tile_order(tt->d_cost[0], tt->d_order_alt, tt->count, tiles_x,
+            !hip_ok(kifs::launch_tile_order(tt->d_cost[0], tt->d_order_alt, tt->count, tiles_x, tt->cost_shift,
                                             c->side_stream), "tile_order_kernel launch") ||
             !hip_ok(hipEventRecord(tt->sorted, c->side_stream), "record(sorted)"))
             return KIFS_ERR_RUNTIME;
@@ -874,6 +918,8 @@ int kifs_render(kifs_ctx* c, uint8_t* out, size_t pitch, int y0, int y1, int enc
 double kifs_last_kernel_ms(kifs_ctx* c) { return c ? c->last_ms : -1.0; }
 
 int kifs_debug_last_round_steps(kifs_ctx* c) { return c ? c->last_round_steps : -1; }
+
+int kifs_debug_last_group_tiles(kifs_ctx* c) { return c ? c->last_group_tiles : -2; }
 
 int kifs_set_frames_in_flight(kifs_ctx* c, int n) {
     if (!c || n < 1) return KIFS_ERR_BAD_ARG;

@@ -9,9 +9,10 @@ namespace kifs {
 
 hipError_t launch_render(const BatchParams& B, uint32_t group, uint32_t primitive,
                          hipStream_t stream);
-// Device-side counting sort: order[] = tile ids (x | y << 16) by descending cost[]; clears cost[].
+// Device-side counting sort: order[] = tile ids (x | y << 16) by descending cost[] >> shift (1024 bins);
+// clears cost[].
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_count,
-                             uint32_t tiles_x, hipStream_t stream);
+                             uint32_t tiles_x, uint32_t shift, hipStream_t stream);
 // Packed row shards -> frame rows: stripe s of shard f (8 rows at src + f * src_shard_stride + 8 s *
 // src_pitch) goes to frame rows stripe_rows[s].. of dst + f * dst_frame_stride.
 hipError_t launch_unpack_stripes(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint8_t* src,

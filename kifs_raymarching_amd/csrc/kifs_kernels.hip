@@ -181,9 +181,12 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     __shared__ uint32_t s_tile[T][TILE_H][TILE_W];
     __shared__ uint32_t s_tiles[T];  // the group's tiles (x | y << 16), 0xffffffff past the table's end
     __shared__ int s_rows[T];        // first frame row of each of them
-    // queue entry: pixel (tile-in-group << 8 | ly << 5 | lx), t, direction
+    // queue entry: pixel (tile-in-group << 8 | ly << 5 | lx) and t; the direction is recomputed from the
+    // pixel every round (~55 instructions against the ~3400 of a round): 8 bytes per ray instead of 20 let
+    // seven workgroups share a CU instead of five, and it is resident workgroups -- each, for most of its
+    // life, one wave marching a thin tail of long rays -- that set a batched launch's rate
     __shared__ uint32_t q_pix[2][CAP];
-    __shared__ float q_t[2][CAP], q_dx[2][CAP], q_dy[2][CAP], q_dz[2][CAP];
+    __shared__ float q_t[2][CAP];
     __shared__ uint32_t h_pix[CAP];  // hit list: pixel and t (the direction is recomputed)
     __shared__ float h_t[CAP];
     // three counters for two buffers: round r reads count[r % 3], appends under count[(r + 1) % 3] and
@@ -238,9 +241,6 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             const uint32_t i = base + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
             q_pix[0][i] = (uint32_t(j) << 8) | (uint32_t(ly) << 5) | uint32_t(lx);
             q_t[0][i] = 0.0f;
-            q_dx[0][i] = dir.x;
-            q_dy[0][i] = dir.y;
-            q_dz[0][i] = dir.z;
         }
     }
     __syncthreads();
@@ -265,7 +265,8 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             if (have) {
                 pix = q_pix[cur][idx];
                 t = q_t[cur][idx];
-                dir = V3{q_dx[cur][idx], q_dy[cur][idx], q_dz[cur][idx]};
+                const uint32_t tile = s_tiles[pix >> 8];
+                dir = ray_direction(P, int(tile & 0xffffu) * TILE_W + int(pix & 31u), s_rows[pix >> 8] + int((pix >> 5) & 7u));
             }
             // a ray that has advanced has t > 0 (epsilon > 0 on this path), and then its position
             // is what the march last computed: fma(t, dir, origin)
@@ -304,9 +305,6 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
                 const uint32_t i = bq + uint32_t(__builtin_popcountll(mq & below));
                 q_pix[cur ^ 1u][i] = pix;
                 q_t[cur ^ 1u][i] = t;
-                q_dx[cur ^ 1u][i] = dir.x;
-                q_dy[cur ^ 1u][i] = dir.y;
-                q_dz[cur ^ 1u][i] = dir.z;
             }
         }
         trips = limit;
@@ -375,6 +373,156 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     }
 }
 
+// render_wave_kernel<GROUP, PRIM>: the throughput path with ONE WAVE per workgroup and tile.
+//   In a batched launch the workgroups that matter spend most of their life as one wave marching a
+//   thin tail of long rays while their other three waves are parked at the round barrier, and it is
+//   workgroup SLOTS -- six 256-thread workgroups per CU with these kernels' SGPR budget -- that the
+//   device runs out of: average residency 1.1 waves per SIMD.  A single-wave workgroup holds a quarter
+//   of the slot: four times as many tails march side by side, the hardware's own dispatcher hands the
+//   next tile of the cost order to whichever CU has room (no software queue could do that cheaper),
+//   and there is nothing to wait for -- no barrier, no atomic.
+//   The wave keeps its tile's live rays in an LDS queue (pixel and t; the direction is recomputed from
+//   the pixel every round) and marches them in rounds of `round_steps` steps, 64 rays at a time: four
+//   chunks at first, one soon after; survivors go to the next round's queue, hits to a list that is
+//   shaded at the end, 64 at a time.  Same arithmetic per ray as everywhere else, same pixels.
+template <int GROUP, int PRIM>
+__global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
+    constexpr uint32_t CAP = TILE_W * TILE_H;  // every pixel of the tile could be a live ray
+    __shared__ float s_srgb[256];
+    __shared__ uint32_t s_tile[TILE_H][TILE_W];
+    __shared__ uint32_t q_pix[2][CAP];  // ly << 5 | lx
+    __shared__ float q_t[2][CAP];
+    __shared__ uint32_t h_pix[CAP];     // hit list
+    __shared__ float h_t[CAP];
+
+    const uint32_t batch = uint32_t(B.count);
+    const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
+    const uint32_t slot = batch > 1 ? blockIdx.x / batch : blockIdx.x;
+    const FrameParams P = batch_frame(B, view);
+    const uint32_t lane = threadIdx.x;
+    const bool srgb = (P.encode == 1);
+    const bool feedback = P.tile_cost != nullptr;
+    const unsigned long long t_start = feedback ? __builtin_amdgcn_s_memtime() : 0ull;
+    const uint32_t tile = P.tile_order[slot];  // scalar load
+    const int tile_x = int(tile & 0xffffu) * TILE_W;
+    const int tile_y = int(tile >> 16) * TILE_H;         // row offset within the launch's rows
+    const int frame_y = tile_frame_row(P, tile >> 16);   // the tile's first frame row
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (srgb) {
+#pragma unroll
+        for (uint32_t i = 0; i < 256; i += 64) s_srgb[i + lane] = P.srgb_table[i + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < TILE_H; r += 2) s_tile[r + int(lane >> 5)][lane & 31u] = P.background_rgba;
+
+    // ---- round 0's queue: the rays that survive the culls, block by block
+    uint32_t n = 0;  // wave-uniform throughout (sums of ballot counts)
+    for (int b = 0; b < TILE_W / 8; ++b) {
+        const int lx = (b << 3) | int(lane & 7u), ly = int(lane >> 3);
+        const int x = tile_x + lx, y = frame_y + ly;
+        const bool valid = (x < P.width) && (y < P.y1);
+        if (wave_is_culled(P, x, y, valid) || __ballot(valid) == 0ull) continue;  // wave-uniform
+        const V3 dir = ray_direction(P, x, y);
+        bool alive = valid && (0 < P.max_iterations) && (0.0f < P.max_distance);
+        if (P.cull_n2 > 0.0f) alive = alive && !ray_never_inside(P, dir);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+        if (alive) {
+            const uint32_t i = n + uint32_t(__builtin_popcountll(m & below));
+            q_pix[0][i] = (uint32_t(ly) << 5) | uint32_t(lx);
+            q_t[0][i] = 0.0f;
+        }
+        n += uint32_t(__builtin_popcountll(m));
+    }
+    __syncthreads();  // one wave: orders the LDS traffic, costs nothing
+
+    // ---- rounds
+    uint32_t hits = 0;
+    int trips = 0;
+    for (uint32_t cur = 0; n != 0u; cur ^= 1u) {
+        const int limit = min(trips + P.round_steps, P.max_iterations);
+        uint32_t n_next = 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+            const bool have = c0 + lane < n;
+            uint32_t pix = 0;
+            float t = 0.0f;
+            V3 dir{0.0f, 0.0f, 1.0f};
+            if (have) {
+                pix = q_pix[cur][c0 + lane];
+                t = q_t[cur][c0 + lane];
+                dir = ray_direction(P, tile_x + int(pix & 31u), frame_y + int(pix >> 5));
+            }
+            // a ray that has advanced has t > 0 (epsilon > 0 on this path) and sits at fma(t, dir, origin)
+            V3 p = (trips == 0) ? P.origin
+                                : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y), fmaf_(t, dir.z, P.origin.z)};
+            bool hit = false, marching = have;
+            int wave_trips = trips;
+            march_round<GROUP, PRIM>(P, dir, t, p, hit, marching, wave_trips, limit);
+            __builtin_amdgcn_s_setprio(0);
+            const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
+            const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);
+            if (hit) {
+                const uint32_t i = hits + uint32_t(__builtin_popcountll(mh & below));
+                h_pix[i] = pix;
+                h_t[i] = t;
+            } else if (marching) {
+                const uint32_t i = n_next + uint32_t(__builtin_popcountll(mq & below));
+                q_pix[cur ^ 1u][i] = pix;
+                q_t[cur ^ 1u][i] = t;
+            }
+            hits += uint32_t(__builtin_popcountll(mh));
+            n_next += uint32_t(__builtin_popcountll(mq));
+        }
+        trips = limit;
+        n = n_next;
+        __syncthreads();
+    }
+
+    // ---- shade the hits, 64 at a time
+    for (uint32_t i0 = 0; i0 < hits; i0 += 64u) {
+        if (i0 + lane < hits) {
+            const uint32_t pix = h_pix[i0 + lane];
+            const float t = h_t[i0 + lane];
+            const int hx = int(pix & 31u), hy = int(pix >> 5);
+            const V3 dir = ray_direction(P, tile_x + hx, frame_y + hy);
+            const V3 p = (t == 0.0f) ? P.origin
+                                     : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                                          fmaf_(t, dir.z, P.origin.z)};
+            const V3 colour = shade_hit<GROUP, PRIM>(P, p);
+            uint32_t r, g, b;
+            if (srgb) {
+                r = srgb8(colour.x, s_srgb);
+                g = srgb8(colour.y, s_srgb);
+                b = srgb8(colour.z, s_srgb);
+            } else {
+                r = unorm8(colour.x);
+                g = unorm8(colour.y);
+                b = unorm8(colour.z);
+            }
+            s_tile[hy][hx] = r | (g << 8) | (b << 16) | 0xff000000u;
+        }
+    }
+    __syncthreads();
+
+    // ---- store: two full 128-byte rows per instruction; cost of the tile: the wave's run time
+#pragma unroll
+    for (int r = 0; r < TILE_H; r += 2) {
+        const int sx = int(lane & 31u), sy = r + int(lane >> 5);
+        const int ox = tile_x + sx;
+        if (ox < P.width && (frame_y + sy) < P.y1)
+            P.out[out_row(P, frame_y + sy, tile_y + sy) * P.pitch_words + uint32_t(ox)] = s_tile[sy][sx];
+    }
+    if (feedback) {
+        const unsigned long long cycles = __builtin_amdgcn_s_memtime() - t_start;
+        const uint32_t cost = uint32_t(min(cycles > 4096ull ? (cycles - 4096ull) >> 10 : 0ull, 1ull << 20));
+        if (lane == 0) {
+            const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
+            uint32_t* cs = &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)];
+            if (batch > 1) atomicMax(cs, cost);  // the batch's views share the table (the sort clears it)
+            else *cs = cost;
+        }
+    }
+}
+
 // The bunny primitive with four lanes per pixel (see bunny_sdf_quad in kifs_scene.hpp): a
 // workgroup renders a quarter of a 32 x 8 tile, rows [2 sub, 2 sub + 2); wave w owns the 8 x 2
 // pixels at columns [8w, 8w + 8), lane -> pixel lane >> 2, column group lane & 3.  Same tile
@@ -439,10 +587,11 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const BatchPar
 
 // Dynamic LDS requested only to cap how many workgroups share a CU (the kernel never touches
 // it); the cap itself is decided on the host (residency_for() in kifs_api.cpp).
-// KIFS_LDS_PAD=<bytes> overrides it (tuning).
+// KIFS_LDS_PAD=<bytes> overrides it (tuning; honoured only with KIFS_TUNING=1).
 static unsigned residency_pad_bytes(int workgroups_per_cu) {
     static const long forced = [] {
-        const char* e = std::getenv("KIFS_LDS_PAD");
+        const char* on = std::getenv("KIFS_TUNING");
+        const char* e = (on && on[0] == '1') ? std::getenv("KIFS_LDS_PAD") : nullptr;
         return e ? std::strtol(e, nullptr, 10) : -1L;
     }();
     if (forced >= 0) return unsigned(forced);
@@ -473,6 +622,10 @@ static hipError_t launch_variant(const BatchParams& B, hipStream_t stream) {
             if (attr != hipSuccess) return attr;
             if (dev >= 0 && dev < 64) opted_in[dev] = true;
         }
+    }
+    if (P.round_steps > 0 && P.group_tiles == 0) {  // the throughput path, one wave per tile
+        hipLaunchKernelGGL((render_wave_kernel<GROUP, PRIM>), dim3(P.tile_count * uint32_t(B.count)), dim3(64), 0, stream, B);
+        return hipGetLastError();
     }
     if (P.round_steps > 0) {  // the throughput path: rays re-queued, one or two tiles per workgroup
         if (P.group_tiles >= 2) {
@@ -535,7 +688,7 @@ hipError_t launch_render(const BatchParams& B, uint32_t group, uint32_t primitiv
 // stale or garbage cost table can only cost speed, never pixels.
 __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* __restrict__ cost,
                                                           uint32_t* __restrict__ order, uint32_t n,
-                                                          uint32_t tiles_x) {
+                                                          uint32_t tiles_x, uint32_t shift) {
     constexpr uint32_t BINS = 1024, LAST = BINS - 1;  // bin 0 = heaviest, LAST = cost 0
     __shared__ uint32_t bins[BINS];
     __shared__ uint32_t wave_total[16];
@@ -548,7 +701,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* __restrict__
     for (uint32_t k = 0; k < rounds; ++k) {
         const uint32_t i = k * 1024u + tid;
         const bool live = i < n;
-        const uint32_t bin = live ? LAST - min(cost[i], LAST) : 0u;
+        const uint32_t bin = live ? LAST - min(cost[i] >> shift, LAST) : 0u;
         const bool zero = live && bin == LAST;
         const unsigned long long zmask = __builtin_amdgcn_ballot_w64(zero);
         if (lane == 0 && zmask) atomicAdd(&bins[LAST], uint32_t(__builtin_popcountll(zmask)));
@@ -571,7 +724,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* __restrict__
     for (uint32_t k = 0; k < rounds; ++k) {
         const uint32_t i = k * 1024u + tid;
         const bool live = i < n;
-        const uint32_t bin = live ? LAST - min(cost[i], LAST) : 0u;
+        const uint32_t bin = live ? LAST - min(cost[i] >> shift, LAST) : 0u;
         const bool zero = live && bin == LAST;
         const unsigned long long zmask = __builtin_amdgcn_ballot_w64(zero);
         uint32_t zbase = 0;
@@ -588,9 +741,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* __restrict__
 }
 
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_count,
-                             uint32_t tiles_x, hipStream_t stream) {
+                             uint32_t tiles_x, uint32_t shift, hipStream_t stream) {
     if (tile_count == 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, tile_count, tiles_x);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, tile_count, tiles_x, shift);
     return hipGetLastError();
 }
 

@@ -66,7 +66,9 @@ struct FrameParams {
     // Ray re-queuing (render_kernel): march steps per round between two re-packings of the
     // workgroup's surviving rays into full waves; 0 = every wave marches its own 64 pixels to the end.
     int round_steps;
-    int group_tiles;                    // tiles (consecutive entries of the order) per workgroup of that path: 1 or 2
+    // tiles (consecutive entries of the order) per 256-thread workgroup of that path: 1 or 2;
+    // 0: one single-wave workgroup per tile (render_wave_kernel)
+    int group_tiles;
     // Host-side launch hint, not read by the kernels: how many workgroups may share a CU
     // (0 = no cap).  See residency_for() in kifs_api.cpp.
     int workgroups_per_cu;

@@ -350,6 +350,11 @@ class GraphicState:
         """Round length of the ray re-queuing in the latest launch (0: one wave per block)."""
         return int(lib.kifs_debug_last_round_steps(self._ctx))
 
+    def debug_last_group_tiles(self) -> int:
+        """Latest launch: 0 = one wave per tile (render_wave_kernel), 1 / 2 = tiles per 256-thread
+        workgroup (render_group_kernel), -1 = no ray re-queuing."""
+        return int(lib.kifs_debug_last_group_tiles(self._ctx))
+
     def set_frames_in_flight(self, n: int):
         """Scheduling hint: the caller keeps n frames in flight on this device (one context and
         stream each).  n > 1 trades the lone-frame residency cap for throughput."""

@@ -1,4 +1,5 @@
 #!/bin/bash
+export KIFS_TUNING=1  # the overrides below are honoured only with this set
 # Residency / feedback sweep of one workload: tools/sweep_pad.sh <workload> [bench flags]
 w=$1; shift
 run() { python bench.py --workload $w --steps 60 --warmup 12 --cpu-seconds 0 "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['kernel_ms'])"; }

@@ -1,4 +1,5 @@
 #!/bin/bash
+export KIFS_TUNING=1  # the overrides below are honoured only with this set
 # Round length of the ray re-queuing (KIFS_ROUND_STEPS; 0 = one wave per block): tools/sweep_rounds.sh
 run() { python bench.py --cpu-seconds 0 "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   ', d['config']['workload'], 'B', d['config']['frames_per_launch'], 'ms/step', d['ms_per_step'], 'Mpix/s', d['value'])"; }
 for k in 0 8 16 32 64; do
