@@ -392,8 +392,10 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     __shared__ uint32_t s_tile[TILE_H][TILE_W];
     __shared__ uint32_t q_pix[2][CAP];  // ly << 5 | lx
     __shared__ float q_t[2][CAP];
-    __shared__ uint32_t h_pix[CAP];     // hit list
-    __shared__ float h_t[CAP];
+    // The hit list grows down from the top of buffer 1 (hit i at index CAP - 1 - i).  Every pixel is a live
+    // ray, a hit or finished, so live rays + hits <= CAP: the list never meets the next round's queue
+    // growing up from 0, nor -- chunks are read in ascending order before their hits are filed -- the part
+    // of this round's queue still to be read.
 
     const uint32_t batch = uint32_t(B.count);
     const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
@@ -461,9 +463,9 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
             const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
             const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);
             if (hit) {
-                const uint32_t i = hits + uint32_t(__builtin_popcountll(mh & below));
-                h_pix[i] = pix;
-                h_t[i] = t;
+                const uint32_t i = CAP - 1u - (hits + uint32_t(__builtin_popcountll(mh & below)));
+                q_pix[1][i] = pix;
+                q_t[1][i] = t;
             } else if (marching) {
                 const uint32_t i = n_next + uint32_t(__builtin_popcountll(mq & below));
                 q_pix[cur ^ 1u][i] = pix;
@@ -480,8 +482,8 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     // ---- shade the hits, 64 at a time
     for (uint32_t i0 = 0; i0 < hits; i0 += 64u) {
         if (i0 + lane < hits) {
-            const uint32_t pix = h_pix[i0 + lane];
-            const float t = h_t[i0 + lane];
+            const uint32_t pix = q_pix[1][CAP - 1u - (i0 + lane)];
+            const float t = q_t[1][CAP - 1u - (i0 + lane)];
             const int hx = int(pix & 31u), hy = int(pix >> 5);
             const V3 dir = ray_direction(P, tile_x + hx, frame_y + hy);
             const V3 p = (t == 0.0f) ? P.origin
