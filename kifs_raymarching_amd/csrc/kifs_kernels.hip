@@ -393,9 +393,11 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     __shared__ uint32_t q_pix[2][CAP];  // ly << 5 | lx
     __shared__ float q_t[2][CAP];
     // The hit list grows down from the top of buffer 1 (hit i at index CAP - 1 - i).  Every pixel is a live
-    // ray, a hit or finished, so live rays + hits <= CAP: the list never meets the next round's queue
-    // growing up from 0, nor -- chunks are read in ascending order before their hits are filed -- the part
-    // of this round's queue still to be read.
+    // ray, a hit or finished, so (rays at the start of a round) + (hits before it) <= CAP.  When buffer 1
+    // receives the next round's queue (growing up from 0) the two cannot meet.  When buffer 1 holds THIS
+    // round's queue [0, n), its chunks are taken from the top down: after the chunks above index c the
+    // list has grown by at most n - c entries, so it ends at or above CAP - (hits before) - (n - c) >= c,
+    // clear of the part [0, c) still to be read.
 
     const uint32_t batch = uint32_t(B.count);
     const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     for (uint32_t cur = 0; n != 0u; cur ^= 1u) {
         const int limit = min(trips + P.round_steps, P.max_iterations);
         uint32_t n_next = 0;
-        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        for (uint32_t c0 = ((n - 1u) >> 6) << 6;; c0 -= 64u) {  // top chunk first (see the hit list above)
             const bool have = c0 + lane < n;
             uint32_t pix = 0;
             float t = 0.0f;
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
             }
             hits += uint32_t(__builtin_popcountll(mh));
             n_next += uint32_t(__builtin_popcountll(mq));
+            if (c0 == 0u) break;
         }
         trips = limit;
         n = n_next;

@@ -1,7 +1,10 @@
 """Randomised GPU-vs-oracle parity: scenes drawn from the GUI's parameter ranges
 (render/gui.rs:24-105: max_iterations 1..=1000, max_distance 10..=10000, epsilon 1e-6..=1,
 power 1..=10, constant in [-1,1]^4) plus random camera poses, every pipeline and primitive,
-both colour targets, ragged frame sizes.  Seeded: the same 40 scenes every run."""
+both colour targets, ragged frame sizes; every fifth camera sits ON the bounding sphere
+(origin_distance = min_distance = 2, data.rs:105-113).  Seeded: the same scenes every run.
+A second family renders BATCHES of views large enough to take the throughput kernels
+(render_group_kernel, render_wave_kernel), which the small frames of the first never reach."""
 import numpy as np
 import pytest
 
@@ -21,21 +24,83 @@ def scenes(K, n=40, seed=20250904):
         w = int(rng.integers(17, 120 if not heavy else 64))
         h = int(rng.integers(9, 90 if not heavy else 48))
         gui = K.GuiData(
-            max_iterations=int(rng.integers(1, 200 if not heavy else 48)),
+            # (log-uniform over the GUI's 1..=1000, capped where the oracle would take minutes)
+            max_iterations=int(10 ** rng.uniform(0, 3.0 if not heavy else 1.7)),
             max_distance=float(10 ** rng.uniform(1, 4)),
-            epsilon=float(10 ** rng.uniform(-6, -1.5)),
+            epsilon=float(10 ** rng.uniform(-6, 0)),
             fractal_color=tuple(int(v) for v in rng.integers(0, 256, 3)),
             background_color=tuple(int(v) for v in rng.integers(0, 256, 3)),
             is_heatmap=bool(rng.integers(0, 4) == 0),
             fractal_group=group, primitive_shape=prim,
             power=float(rng.uniform(1, 10)),
             constant=tuple(float(v) for v in rng.uniform(-1, 1, 4)))
-        cam = K.CameraData(origin_distance=float(rng.uniform(2.0, 8.0)),
+        cam = K.CameraData(origin_distance=2.0 if i % 5 == 4 else float(rng.uniform(2.0, 8.0)),
                            phi=float(rng.uniform(0, 2 * np.pi)), theta=float(rng.uniform(-1.5, 1.5)))
         iters = (int(rng.integers(0, 40 if not heavy else 8)), int(rng.integers(0, 12 if not heavy else 4)),
                  int(rng.integers(0, 24)))
         out.append((K.ScreenData(w, h), cam, gui, iters, int(rng.integers(0, 2))))
     return out
+
+
+def big_scenes(K, n=12, seed=20261004):
+    """Batched launches of >= 4096 workgroups: (screen, cameras, gui, iters, encode, expected shape) with
+    shape 0 = render_wave_kernel (many views, cameras on the bounding sphere: every tile is heavy), 1 / 2 =
+    tiles per workgroup of render_group_kernel."""
+    rng = np.random.default_rng(seed)
+    FG, PS = K.FractalGroup, K.PrimitiveShape
+    out = []
+    for i in range(n):
+        group = [FG.JuliaSet, FG.KaleidoscopicIFS, FG.JuliaSet, FG.KaleidoscopicIFS, FG.GeneralizedJuliaSet][i % 5]
+        prim = [PS.SierpinskiTetrahedron, PS.Torus, PS.Box, PS.Sphere, PS.Cylinder][int(rng.integers(0, 5))]
+        wave = i % 3 == 0 and group != FG.GeneralizedJuliaSet
+        w, h = int(rng.integers(600, 700)), int(rng.integers(400, 450))  # 19..22 x 50..57 tiles >= 1000
+        if wave:  # comfortably past the load at which the library switches to one wave per tile
+            w, h = int(rng.integers(800, 900)), int(rng.integers(500, 560))
+        julia = group == FG.JuliaSet
+        views = (16 if julia else 32) if wave else int(rng.integers(5, 9))
+        gui = K.GuiData(
+            max_iterations=int(rng.integers(40, 300)) if group != FG.GeneralizedJuliaSet else int(rng.integers(20, 40)),
+            max_distance=float(10 ** rng.uniform(1, 4)),
+            epsilon=float(10 ** rng.uniform(-5, -1)),
+            fractal_color=tuple(int(v) for v in rng.integers(0, 256, 3)),
+            background_color=tuple(int(v) for v in rng.integers(0, 256, 3)),
+            fractal_group=group, primitive_shape=prim, power=float(rng.uniform(1, 10)),
+            constant=tuple(float(v) for v in rng.uniform(-1, 1, 4)))
+        # wave scenes: a camera on (Julia, B = 2) or inside (the primitives' B is 1 .. 2.24) the bounding
+        # sphere, so that every tile of the frame counts as heavy
+        d = (2.0 if julia else 1.2) if wave else float(rng.uniform(2.5, 6.0))
+        cams = [K.CameraData(origin_distance=d, min_distance=1.0, phi=float(rng.uniform(0, 2 * np.pi)), theta=float(rng.uniform(-1.2, 1.2)))
+                for _ in range(views)]
+        iters = (int(rng.integers(1, 30)) if group != FG.GeneralizedJuliaSet else int(rng.integers(1, 6)),
+                 int(rng.integers(0, 12)) if group != FG.GeneralizedJuliaSet else int(rng.integers(0, 3)),
+                 int(rng.integers(0, 20)))
+        load = w * h // 256 * views  # cameras on the sphere: every tile counts
+        shape = 0 if wave else (2 if group != FG.GeneralizedJuliaSet else 1)
+        assert not wave or load >= 32000 or (julia and load >= 16000)
+        out.append((K.ScreenData(w, h), cams, gui, iters, int(rng.integers(0, 2)), shape))
+    return out
+
+
+@pytest.mark.parametrize("index", range(12))
+def test_random_batch_bit_exact_on_the_throughput_kernels(index, gs, kifs, oracle):
+    import torch
+    screen, cams, gui, iters, encode, shape = big_scenes(kifs)[index]
+    W, H = screen.width, screen.height
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(*iters)
+    outs = torch.zeros((len(cams), H, W, 4), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    gs.render_batch_async([outs[i] for i in range(len(cams))], cams, stream=stream, encode=encode)
+    stream.synchronize()
+    assert gs.debug_last_round_steps() > 0, "the launch was meant to re-queue its rays"
+    if shape == 0 or gs.debug_last_group_tiles() == 0:
+        assert gs.debug_last_group_tiles() == shape, (gs.debug_last_group_tiles(), shape)
+    got = outs.cpu().numpy()
+    for k in sorted({0, len(cams) // 2, len(cams) - 1, int(index) % len(cams)}):
+        want = oracle_frame(oracle, kifs, screen, cams[k], gui, iters, encode=encode)
+        rep = diff_report(got[k], want)
+        assert rep["mismatched_pixels"] == 0, (index, k, gui, cams[k], iters, rep)
 
 
 @pytest.mark.parametrize("index", range(40))

@@ -206,3 +206,29 @@ def test_feedback_survives_a_change_of_pipeline(gs, kifs, oracle):
         assert (out.cpu().numpy() == want).all(), cycle
     order = gs.debug_get_tile_order()
     assert len({int(o) for o in order}) == 60 * 135
+
+
+@pytest.mark.parametrize("prim", ["Sphere", "Box", "SierpinskiTetrahedron"])
+def test_wave_kernel_with_every_pixel_live_and_hitting(prim, gs, kifs, oracle):
+    """render_wave_kernel keeps its hit list in the same LDS buffer as a ray queue.  The worst case for that
+    layout: a camera on the bounding sphere looking at a solid that fills the frame -- all 256 rays of a
+    tile live, whole chunks hitting in the same round."""
+    import torch
+    PS = kifs.PrimitiveShape
+    gui = kifs.GuiData(primitive_shape=PS[prim], max_iterations=120, epsilon=1e-3, fractal_color=(250, 180, 90))
+    screen = kifs.ScreenData(1024, 528)  # 32 x 66 tiles x 32 views: past the load at which KIFS launches go one wave per tile
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(100, 10, 6)
+    cams = [kifs.CameraData(origin_distance=2.0 if prim != "Sphere" else 1.2, min_distance=1.0, phi=0.21 * k,
+                            theta=0.05 * k - 0.7) for k in range(32)]
+    outs = torch.zeros((32, 528, 1024, 4), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    gs.render_batch_async([outs[i] for i in range(32)], cams, stream=stream)
+    stream.synchronize()
+    assert gs.debug_last_group_tiles() == 0 and gs.debug_last_round_steps() > 0
+    got = outs.cpu().numpy()
+    for k in (0, 13, 31):
+        want = oracle_frame(oracle, kifs, screen, cams[k], gui, (100, 10, 6))
+        assert (want != want[0, 0]).any(-1).mean() > 0.05, "the solid should be in view"
+        assert (got[k] == want).all(), (prim, k, int((got[k] != want).any(-1).sum()))
