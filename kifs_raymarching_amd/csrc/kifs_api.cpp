@@ -588,16 +588,18 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         //     batched 1080p Julia 0.319 -> 0.281 ms; below 3 500 heavy tiles pairing only halves the
         //     workgroups that can run side by side: 720p x8 at distance 5, 0.222 -> 0.188 ms with one) or a
         //     big lone KIFS frame (1440p Sierpinski at distance 2: -11 %), else ONE.
-        // Not the bunny (four lanes per ray, 216 VGPRs: pairs just run longer) and not the generalised
-        // Julia below the wave kernel's range (its few, very long workgroups lose 7 % when paired).
+        // Not the bunny (four lanes per ray, 216 VGPRs: pairs just run longer); the generalised Julia pairs
+        // tiles only from 12 000 heavy tiles (1080p x32: 0.140 -> 0.125 ms per frame; x8: nothing, and its
+        // few, very long workgroups lost 7 % when paired on smaller launches) and keeps 256-thread
+        // workgroups throughout (one wave per tile: x32 0.150 ms, x8 0.31 against 0.22).
         static const int forced = tuning_knob("KIFS_GROUP_TILES");
         const bool julia = group_id == uint32_t(kifs::GROUP_JULIA);
         const bool genjulia = group_id == uint32_t(kifs::GROUP_GENJULIA);
         const bool kifs_scene = group_id == uint32_t(kifs::GROUP_KIFS);
         const double wave_from = lone ? 30000.0 : (julia ? 16000.0 : 32000.0);
         int shape = 1;
-        if (load >= wave_from) shape = 0;
-        else if (!lone && !genjulia && load >= 3500.0) shape = 2;
+        if (load >= wave_from && !genjulia) shape = 0;
+        else if (!lone && load >= (genjulia ? 12000.0 : 3500.0)) shape = 2;
         else if (lone && kifs_scene && load >= 12000.0) shape = 2;
         if (forced >= 0) shape = forced;
         if (bunny_scene) shape = 1;

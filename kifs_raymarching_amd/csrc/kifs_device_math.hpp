@@ -275,6 +275,78 @@ KIFS_DEV float acos_(float x) {
     return PIO2_F - asin_poly(x, x * x);
 }
 
+// ---- wave-guarded forms --------------------------------------------------------
+// log2_, exp2_ and acos_ start with special-case tests and (acos_) a three-way range split; compiled
+// as written each is a chain of divergent branches.  These forms return the same bits -- the same
+// operations on the same operands -- but decide once per WAVE whether any lane needs the general
+// code (NaN, infinities, zeros, denormals, out-of-range arguments: practically never inside an
+// orbit) and otherwise run straight-line code with the range split done by selects.
+KIFS_DEV float log2_wave(float x) {
+    const bool ordinary = (x >= 1.17549435e-38f) && (x <= 3.40282347e38f);  // positive normal
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return log2_(x);
+    int e;
+    float m = log_reduce(x, e);
+    float z = m * m;
+    float y = (log_poly(m) * m) * z;
+    y = fmaf_(-0.5f, z, y);
+    const float L = 0.44269504088896340735992f;  // log2(e) - 1
+    float r = y * L;
+    r = fmaf_(m, L, r);
+    r = r + y;
+    r = r + m;
+    return r + float(e);
+}
+
+KIFS_DEV float exp2_wave(float x) {
+    const bool ordinary = (x <= 127.99999f) && (x >= -150.0f);  // false for NaN
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return exp2_(x);
+    float n = rint_(x);
+    float r = x - n;
+    float p = 1.535336188319500E-004f;
+    p = fmaf_(p, r, 1.339887440266574E-003f);
+    p = fmaf_(p, r, 9.618437357674640E-003f);
+    p = fmaf_(p, r, 5.550332471162809E-002f);
+    p = fmaf_(p, r, 2.402264791363012E-001f);
+    p = fmaf_(p, r, 6.931472028550421E-001f);
+    p = fmaf_(p, r, 1.0f);
+    int ni = int(n);
+    int n1 = ni / 2, n2 = ni - n1;
+    float s1 = from_bits(uint32_t(n1 + 127) << 23);
+    float s2 = from_bits(uint32_t(n2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+KIFS_DEV float acos_wave(float x) {
+    const bool ordinary = (x >= -1.0f) && (x <= 1.0f);  // false for NaN
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return acos_(x);
+    const float PI_F = 3.14159265358979323846f;
+    const float PIO2_F = 1.57079632679489661923f;
+    const bool hi = x > 0.5f, lo = x < -0.5f;
+    // |x| > 0.5: z = (1 - |x|) / 2 written as acos_ writes it for each sign
+    const float zt = 0.5f * (hi ? (1.0f - x) : (1.0f + x));
+    const bool tail = hi || lo;
+    const float z = tail ? zt : x * x;
+    const float a = tail ? sqrt_(zt) : x;
+    const float r = asin_poly(a, z);
+    const float two_r = 2.0f * r;
+    return hi ? two_r : (lo ? PI_F - two_r : PIO2_F - r);
+}
+
+KIFS_DEV void sincos_wave(float x, float& s, float& c) {
+    const bool ordinary = abs_(x) <= 1048576.0f;  // false for NaN
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) {
+        sincos_(x, s, c);
+        return;
+    }
+    float r;
+    const int q = reduce_pio2(x, r);
+    const float sk = sin_kernel(r), ck = cos_kernel(r);
+    const float ss = (q & 1) ? ck : sk;
+    const float cc = (q & 1) ? sk : ck;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // ---- colour target ---------------------------------------------------------------
 // UNORM8: clamp, scale, +0.5, truncate; NaN -> 0.
 KIFS_DEV uint32_t unorm8(float x) {

@@ -31,16 +31,27 @@ KIFS_DEV V4 quat_sq_add(V4 q, V4 c) {
               fmaf_(tr, q.w, c.w)};
 }
 
-// quaternions.wgsl:57-63
-KIFS_DEV V4 quat_pow(V4 q, float x) {
-    float norm = length(q);
-    float phi = acos_(q.x / norm);
-    V3 n = normalize(V3{q.y, q.z, q.w});
-    float pw = pow_(norm, x);
-    float a = x * phi;
+// quat_pow (quaternions.wgsl:57-63) with the work it shares with its callers made explicit (the
+// arithmetic contract): d = |ijk|^2, qs = |q|^2, L = log2(qs) come from the
+// caller; length(q) = sqrt(qs); the two divisions are products with correctly rounded
+// reciprocals; pow(norm, x) = exp2(x L / 2).  The elementary functions are the wave-guarded forms of
+// kifs_device_math.hpp (one ballot, then straight-line code: this is the inner loop of the slowest
+// pipeline, and a lone wave pays ~35 cycles for every taken branch).
+KIFS_DEV V4 quat_pow_shared(V4 q, float d, float qs, float L, float x) {
+    const float inv = 1.0f / sqrt_(qs);
+    const float phi = acos_wave(q.x * inv);
+    const float ninv = 1.0f / sqrt_(d);
+    const V3 n{q.y * ninv, q.z * ninv, q.w * ninv};
+    const float pw = exp2_wave(x * (0.5f * L));
     float cs, sn;
-    sincos_(a, sn, cs);
+    sincos_wave(x * phi, sn, cs);
     return V4{pw * cs, pw * (n.x * sn), pw * (n.y * sn), pw * (n.z * sn)};
+}
+
+KIFS_DEV V4 quat_pow(V4 q, float x) {
+    const float d = quat_ijk2(q);
+    const float qs = fmaf_(q.x, q.x, d);
+    return quat_pow_shared(q, d, qs, log2_wave(qs), x);
 }
 
 // ---- Julia ---------------------------------------------------------------------
@@ -184,15 +195,18 @@ KIFS_DEV float genjulia_sdf(const FrameParams& P, V3 p) {
     const float n2 = dot(p, p);
     if (n2 > P.bound_n2) return sqrt_(n2) - 2.0f;  // == length(p) > 2 + epsilon
     V4 q{p.x, p.y, p.z, 0.1f};
-    float qs = quat_norm2(q);
+    float d = quat_ijk2(q);
+    float qs = fmaf_(q.x, q.x, d);  // = quat_norm2(q)
     float dqs = 1.0f;
     const float pp = P.power * P.power;
     const float pm1 = P.power - 1.0f;
     for (int i = 0; i < P.sdf_iters; ++i) {
-        dqs = dqs * (pp * pow_(qs, pm1));
-        V4 t = quat_pow(q, P.power);
+        const float L = log2_wave(qs);
+        dqs = dqs * (pp * exp2_wave(pm1 * L));  // pow(qs, power - 1)
+        V4 t = quat_pow_shared(q, d, qs, L, P.power);
         q = V4{t.x + P.c.x, t.y + P.c.y, t.z + P.c.z, t.w + P.c.w};
-        qs = quat_norm2(q);
+        d = quat_ijk2(q);
+        qs = fmaf_(q.x, q.x, d);
         if (qs > P.max_distance) break;
     }
     return (0.25f * log_(qs)) * sqrt_(qs / dqs);
@@ -221,16 +235,15 @@ KIFS_DEV V3 genjulia_normal(const FrameParams& P, V3 p) {
 
 // ---- KIFS ------------------------------------------------------------------------
 // Mirror in a plane through the origin with normal e_a + e_b (kifs.wgsl:6-14 with the
-// normals of :58-62): signed distance (pa+pb)/|n|, reflect only from the negative side.
-KIFS_DEV void mirror_apply(float sd, float& pa, float& pb) {
+// normals of :58-62): signed distance (pa+pb)/|n|, reflect only from the negative side.  The
+// division by the constant |n| = sqrt(2) is a multiplication by fl(1/sqrt(2)): the arithmetic
+// contract's choice, one ulp from the quotient, inside WGSL's bound for `/`.
+KIFS_DEV void mirror2(float& pa, float& pb) {
     const float nn = 1.0f / sqrt_(2.0f);
-    float k = 2.0f * min_(sd, 0.0f);
+    const float sd = (pa + pb) * nn;
+    const float k = 2.0f * min_(sd, 0.0f);
     pa = fmaf_(-k, nn, pa);
     pb = fmaf_(-k, nn, pb);
-}
-
-KIFS_DEV void mirror2(float& pa, float& pb) {
-    mirror_apply((pa + pb) / sqrt_(2.0f), pa, pb);
 }
 
 KIFS_DEV V3 tetrahedral_fold(V3 p) {  // kifs.wgsl:56-66
@@ -240,85 +253,44 @@ KIFS_DEV V3 tetrahedral_fold(V3 p) {  // kifs.wgsl:56-66
     return p;
 }
 
-// x / sqrt(2) with the reciprocal folded into constants: two residual corrections around
-// x * (1/c).  tools/verify/div_const2.c checks all 2^32 inputs: bit-identical to the correctly
-// rounded quotient for every 2^-102 <= |x| < 2^127 (and for NaN); it is NOT exact for tinier
-// values, zeros and infinities (sierpinski_folds screens for those).  This function is the readable
-// statement of the sequence KIFS_MIRROR_SD spells out in assembly.
-KIFS_DEV float div_sqrt2_ranged(float x) {
-    const float c = sqrt_(2.0f);
-    const float inv = 1.0f / c;
-    float q0 = x * inv;
-    float e1 = fmaf_(-c, q0, x);
-    float q1 = fmaf_(e1, inv, q0);
-    float e2 = fmaf_(-c, q1, x);
-    return fmaf_(e2, inv, q1);
-}
-
-// The fold with the ranged division; `lo`/`hi` receive min/max |x| over the three quotients'
-// numerators so that the caller can validate the whole fold with two compares.  (min3/max3
-// skip NaN operands, which is fine: a NaN coordinate gives a NaN estimate on either path.)
-// One mirror of the fold in the long-ray loop below: x = a + b; sd = x / sqrt(2) by the ranged
-// division (q in v46, residuals in v47); m = min(sd, 0) -- the hardware minimum, see below --
-// left in v46 for the caller's two updates  p -= m * (2/sqrt(2)).
-#define KIFS_MIRROR_SD(x, a, b)                                                            \
-    "v_add_f32_e32 " x ", " a ", " b "\n"                                                  \
-    "v_mul_f32_e32 v46, 0x3f3504f3, " x "\n"         /* q0 = x * I */                      \
-    "v_fmamk_f32 v47, v46, 0xbfb504f3, " x "\n"      /* e1 = fma(-c, q0, x) */             \
-    "v_fmac_f32_e32 v46, 0x3f3504f3, v47\n"          /* q1 = fma(e1, I, q0) */             \
-    "v_fmamk_f32 v47, v46, 0xbfb504f3, " x "\n"      /* e2 = fma(-c, q1, x) */             \
-    "v_fmac_f32_e32 v46, 0x3f3504f3, v47\n"          /* q2 = fma(e2, I, q1) */             \
+// One mirror of the fold in the loop below: sd = (a + b) * fl(1/sqrt(2)); m = min(sd, 0) -- the
+// hardware minimum, see below -- left in v46 for the caller's two updates  p -= m * (2/sqrt(2)).
+#define KIFS_MIRROR_SD(a, b)                                                               \
+    "v_add_f32_e32 v46, " a ", " b "\n"                                                    \
+    "v_mul_f32_e32 v46, 0x3f3504f3, v46\n"                                                 \
     "v_min_f32_e32 v46, 0, v46\n"
 
 // One fold + scale step of kifs.wgsl:72-78 for the lanes in EXEC, then EXEC &= n2 < stop.
-//   v[40:41] = [x, y]   v42 = z   v43 = n2   v44 = scale   v45 = smallest numerator key so far
-//   v[46:47] division scratch   v48-v50 numerators   s[76:77] = [-2/sqrt(2), -]
+//   v[40:41] = [x, y]   v42 = z   v43 = n2   v44 = scale   v[46:47] = [m, -]   s[76:77] = [-2/sqrt(2), -]
 #define KIFS_FOLD_STEP                                                                     \
-    KIFS_MIRROR_SD("v48", "v40", "v41")                                                    \
+    KIFS_MIRROR_SD("v40", "v41")                                                           \
     "v_pk_fma_f32 v[40:41], v[46:47], s[76:77], v[40:41] op_sel_hi:[0,0,1]\n"              \
-    KIFS_MIRROR_SD("v49", "v41", "v42")                                                    \
+    KIFS_MIRROR_SD("v41", "v42")                                                           \
     "v_fmac_f32_e32 v41, 0xbfb504f3, v46\n"                                                \
     "v_fmac_f32_e32 v42, 0xbfb504f3, v46\n"                                                \
-    KIFS_MIRROR_SD("v50", "v40", "v42")                                                    \
+    KIFS_MIRROR_SD("v40", "v42")                                                           \
     "v_fmac_f32_e32 v40, 0xbfb504f3, v46\n"                                                \
     "v_fmac_f32_e32 v42, 0xbfb504f3, v46\n"                                                \
-    "v_lshl_add_u32 v48, v48, 1, -1\n"      /* numerator bits without sign, zero -> 2^32-1 */ \
-    "v_lshl_add_u32 v49, v49, 1, -1\n"                                                     \
-    "v_lshl_add_u32 v50, v50, 1, -1\n"                                                     \
-    "v_min3_u32 v45, v48, v49, v45\n"                                                      \
     "v_pk_fma_f32 v[40:41], v[40:41], 2.0, -1.0 op_sel_hi:[1,0,0]\n"   /* p = 2 p - 1 */    \
     "v_fma_f32 v42, v42, 2.0, -1.0\n"                                                      \
-    "v_min_u32_e32 v45, v50, v45\n"                                                        \
     "v_add_f32_e32 v44, v44, v44\n"                                    /* scale *= 2 */     \
     "v_mul_f32_e32 v43, v40, v40\n"                                    /* n2 = dot(p, p) */ \
     "v_fmac_f32_e32 v43, v41, v41\n"                                                       \
     "v_fmac_f32_e32 v43, v42, v42\n"                                                       \
     "v_cmpx_gt_f32_e32 vcc, %[stop], v43\n"
 
-// The fold loop of the Sierpinski estimate, hand-scheduled: 41 instructions per fold where the
-// compiler's version of the same arithmetic has 52 (and a taken branch every fold; here every
-// second).  Exact rewrites make the difference:
-//  * the division by sqrt(2) is div_sqrt2_ranged (above), valid for 2^-102 <= |x| < 2^127.  The
-//    upper bound always holds: a lane folds only while n2 < stop, so n2 is finite, every
-//    coordinate is below 2^64.1 and no numerator can reach 2^67.
-//  * x = +-0 (every pixel on the image diagonal of an axis-aligned view starts with y + z = 0)
-//    is fine too: the sequence returns a zero, possibly of the other sign, the mirror then adds
-//    a signed zero to both coordinates, and p = 2 p - 1 (fma(2, +-0, -1) = -1) forgets the sign
-//    of a zero coordinate before anything but another signed-zero sum can see it.
-//  * what is NOT covered is 0 < |x| < 2^-102.  Each numerator contributes the key
-//    (bits << 1) - 1 (sign dropped; zero wraps to 2^32 - 1) to a running unsigned minimum,
-//    checked once after the loop: a wave with a key below that of 2^-102 (practically never) is
-//    re-evaluated by the caller with true divisions.
-//  * min_(sd, 0) is the hardware minimum: they differ only for sd = -0 (sign of a zero again)
-//    and for NaN, and a NaN numerator means a coordinate is NaN already and stays NaN on both
-//    paths (the estimate is NaN either way);
+// The fold loop of the Sierpinski estimate, hand-scheduled: 20 instructions per fold (the
+// compiler's version of the same arithmetic: 27, and a taken branch every fold; here every second).
+//  * min_(sd, 0) is the hardware minimum: they differ only for sd = -0 (the mirror then adds a
+//    zero of the other sign to both coordinates, and p = 2 p - 1, fma(2, +-0, -1) = -1, forgets the
+//    sign of a zero before anything but another signed-zero sum can see it) and for NaN (a NaN
+//    sum means a coordinate is NaN already and stays NaN on both paths: the estimate is NaN);
 //  * 2 * m is exact, so fma(-(2 m), 1/sqrt(2), p) = fma(m, -(2/sqrt(2)), p) bit for bit.
-// `lanes`: lanes that take part.  Returns false when the result must be recomputed exactly.
-KIFS_DEV bool sierpinski_folds(const FrameParams& P, V3& p, float& n2, float& scale,
-                                unsigned long long lanes) {
+// `lanes`: lanes that take part (the others keep their values).
+KIFS_DEV void sierpinski_folds(const FrameParams& P, V3& p, float& n2, float& scale,
+                               unsigned long long lanes) {
     F2 xy{p.x, p.y}, q;
-    float z = p.z, x1, x2, x3;
-    unsigned lo = 0xffffffffu;
+    float z = p.z;
     const F2 knn{-2.0f * (1.0f / sqrt_(2.0f)), 0.0f};
     int n = P.fold_iters;
     unsigned long long saved_exec;
@@ -343,33 +315,20 @@ KIFS_DEV bool sierpinski_folds(const FrameParams& P, V3& p, float& n2, float& sc
         "s_cbranch_execnz 0b\n"
         "1:\n"
         "s_mov_b64 exec, %[save]\n"
-        : "+{v[40:41]}"(xy), "+{v42}"(z), "+{v43}"(n2), "+{v44}"(scale), "+{v45}"(lo),
-          "=&{v[46:47]}"(q), "=&{v48}"(x1), "=&{v49}"(x2), "=&{v50}"(x3), [save] "=&s"(saved_exec),
-          [n] "+s"(n)
+        : "+{v[40:41]}"(xy), "+{v42}"(z), "+{v43}"(n2), "+{v44}"(scale), "=&{v[46:47]}"(q),
+          [save] "=&s"(saved_exec), [n] "+s"(n)
         : [stop] "s"(P.fold_n2_stop), "{s[76:77]}"(knn), [lanes] "s"(lanes)
         : "vcc", "scc");
     p = V3{xy.x, xy.y, z};
-    return __builtin_amdgcn_ballot_w64(lo < ((25u << 24) - 1u)) == 0ull;  // biased exponent of 2^-102 is 25
 }
 
 // `lanes`: the lanes whose estimate the caller will use (the others get an unspecified value).
 KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p, unsigned long long lanes) {  // kifs.wgsl:68-81
     // The loop condition `r < max_distance` is evaluated on the squared norm (exact: see
     // FrameParams::fold_n2_stop), so the square root is taken once, after the loop.
-    const V3 p0 = p;
     float scale = 1.0f;
     float n2 = dot(p, p);
-    if (__builtin_expect(!sierpinski_folds(P, p, n2, scale, lanes), 0)) {
-        p = p0;
-        scale = 1.0f;
-        n2 = dot(p, p);
-        for (int i = 0; i < P.fold_iters && n2 < P.fold_n2_stop; ++i) {
-            V3 f = tetrahedral_fold(p);
-            p = V3{fmaf_(2.0f, f.x, -1.0f), fmaf_(2.0f, f.y, -1.0f), fmaf_(2.0f, f.z, -1.0f)};
-            scale = scale * 2.0f;
-            n2 = dot(p, p);
-        }
-    }
+    sierpinski_folds(P, p, n2, scale, lanes);
     return (sqrt_(n2) - 2.0f) / scale;
 }
 

@@ -130,15 +130,33 @@ static inline v4 quat_mul(v4 a, v4 b) {
                 fma_(a.x, bi.y, b.x * ai.y) + cr.y, fma_(a.x, bi.z, b.x * ai.z) + cr.z};
 }
 
-/* quat_pow, quaternions.wgsl:57-63 */
-static inline v4 quat_pow(v4 q, float x) {
-    float norm = len4(q);
-    float phi = kor_acosf(q.x / norm);
-    v3 n = normalize3((v3){q.y, q.z, q.w});
-    float pw = kor_powf(norm, x);
+/* quat_pow, quaternions.wgsl:57-63:
+ *     norm = length(q); phi = acos(q.real / norm); n = normalize(q.ijk);
+ *     norm^x * (cos(x phi), n sin(x phi))
+ * with the work it shares with its callers made explicit (contract change of round 2; every step is
+ * a legal evaluation of the WGSL: builtins are ULP-bounded, not exact):
+ *   d  = |ijk|^2 and qs = |q|^2 as in quat_norm2 -- the caller's loop needs them anyway;
+ *   length(q) = sqrt(qs), length(ijk) = sqrt(d): the same sums of squares, one evaluation order;
+ *   L  = log2(qs), taken once: pow(norm, x) = exp2(x log2(norm)) with log2(sqrt(qs)) = L / 2, and
+ *        gen_julia.wgsl:16's pow(qs, power - 1) = exp2((power - 1) L) in the caller;
+ *   a / norm and ijk / length(ijk) as products with the correctly rounded reciprocals (what a shader
+ *        compiler makes of a division by a value used several times; within 1.5 ulp of the quotient).
+ * One log2, two divisions and two dot products less per orbit step than the literal reading. */
+static inline v4 quat_pow_shared(v4 q, float d, float qs, float L, float x) {
+    float inv = 1.0f / sqrtf(qs);
+    float phi = kor_acosf(q.x * inv);
+    float ninv = 1.0f / sqrtf(d);
+    v3 n = {q.y * ninv, q.z * ninv, q.w * ninv};
+    float pw = kor_exp2f(x * (0.5f * L));
     float a = x * phi;
     float cs = kor_cosf(a), sn = kor_sinf(a);
     return (v4){pw * cs, pw * (n.x * sn), pw * (n.y * sn), pw * (n.z * sn)};
+}
+
+static inline v4 quat_pow(v4 q, float x) {
+    float d = quat_ijk2(q);
+    float qs = fma_(q.x, q.x, d);
+    return quat_pow_shared(q, d, qs, kor_log2f(qs), x);
 }
 
 /* ============================ Julia (julia.wgsl) =========================== */
@@ -195,16 +213,19 @@ static float genjulia_sdf(Scene* s, v3 p) {
     float norm = len3(p);
     if (norm > 2.0f + s->epsilon) return norm - 2.0f; /* gen_julia.wgsl:7-10 */
     v4 q = {p.x, p.y, p.z, 0.1f};
-    float qs = quat_norm2(q);
+    float d = quat_ijk2(q);
+    float qs = fma_(q.x, q.x, d);               /* = quat_norm2(q) */
     float dqs = 1.0f;
     float pp = s->power * s->power;
     float pm1 = s->power - 1.0f;
     for (int i = 0; i < s->sdf_iters; i++) {
         s->n_inner++;
-        dqs = dqs * (pp * kor_powf(qs, pm1));   /* :16 */
-        v4 t = quat_pow(q, s->power);           /* :17 */
+        float L = kor_log2f(qs);
+        dqs = dqs * (pp * kor_exp2f(pm1 * L));  /* :16, pow(qs, power - 1) */
+        v4 t = quat_pow_shared(q, d, qs, L, s->power); /* :17 */
         q = (v4){t.x + s->c.x, t.y + s->c.y, t.z + s->c.z, t.w + s->c.w};
-        qs = quat_norm2(q);
+        d = quat_ijk2(q);
+        qs = fma_(q.x, q.x, d);
         if (qs > s->max_distance) break;
     }
     return (0.25f * kor_logf(qs)) * sqrtf(qs / dqs); /* :26 */
@@ -232,13 +253,18 @@ static v3 genjulia_normal(Scene* s, v3 p) {
 
 /* plane_mirror for a plane through the origin whose normal has two unit
  * components a,b and one zero (kifs.wgsl:6-14 with the normals of :58-62).
- *   plane_SDF   = dot(n, p - 0) / length(n) = (pa + pb) / sqrt(2)
+ *   plane_SDF    = dot(n, p - 0) / length(n) = (pa + pb) / sqrt(2)
  *   normalize(n) = n / length(n) -> 1/sqrt(2) on the two live axes, 0 on the third
- *   p - 2*min(sdf,0)*normalize(n): live axes fused, dead axis unchanged. */
+ *   p - 2*min(sdf,0)*normalize(n): live axes fused, dead axis unchanged.
+ * The division by the constant length(n) is evaluated as a multiplication by its correctly
+ * rounded reciprocal nn = fl(1/sqrt(2)) -- what a shader compiler makes of `x / const`, within
+ * one ulp of the quotient and so inside WGSL's 2.5 ULP bound for `/`.  (Contract change of
+ * round 2: the correctly rounded quotient cost the kernels four extra instructions and a range
+ * check per mirror, three mirrors per fold; the NumPy restatement keeps the true division and
+ * tools/parity_envelope.py measures what the choice is worth in pixels.) */
 static inline void mirror2(float* pa, float* pb) {
-    const float len = sqrtf(2.0f);
-    const float nn = 1.0f / len;
-    float sd = (*pa + *pb) / len;
+    const float nn = 1.0f / sqrtf(2.0f);
+    float sd = (*pa + *pb) * nn;
     float k = 2.0f * min_(sd, 0.0f);
     *pa = fma_(-k, nn, *pa);
     *pb = fma_(-k, nn, *pb);
