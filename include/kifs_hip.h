@@ -220,13 +220,14 @@ int kifs_unpack_shard_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t*
 
 /* ---- single-process multi-GPU ------------------------------------------------------
  * For a host that drives all GPUs of a node from one process (the reference's host is one
- * process, application.rs:37-48).  A kifs_multi owns one context per listed device; a render
- * splits the frame into kifs_band_range row bands, launches every band on its own device
- * concurrently and collects them into the frame on the ROOT device (the first one listed) by
- * peer-to-peer copies over xGMI (hipMemcpyPeerAsync; the root renders its band in place).
- * Bands are bit-identical to the same rows of a single-GPU frame.  The multi-process form of
- * the same sharding (one process per GPU, RCCL point-to-point gather) lives above the ABI in
- * kifs_raymarching_amd/bands.py.  A device may be listed more than once (testing on one GPU). */
+ * process, application.rs:37-48).  A kifs_multi owns one context per listed device; a render deals
+ * the frame's 8-row stripes to the devices (kifs_shard_stripes; equal shares unless
+ * kifs_multi_set_weights says otherwise), launches every shard on its own device concurrently --
+ * the ROOT device (the first one listed) straight into the frame -- and the root pulls the other
+ * shards over xGMI (hipMemcpyPeerAsync) and moves their stripes to their frame rows.  The frame is
+ * bit-identical to a single-GPU frame.  The multi-process form of the same sharding (one process
+ * per GPU, RCCL point-to-point gather) lives above the ABI in kifs_raymarching_amd/bands.py.  A
+ * device may be listed more than once (testing on one GPU). */
 typedef struct kifs_multi kifs_multi;
 kifs_multi* kifs_multi_create(const int* device_ordinals, int n_devices, int* status);
 void kifs_multi_destroy(kifs_multi* m);
@@ -235,13 +236,15 @@ int kifs_multi_set_camera(kifs_multi* m, const KifsCameraUniform* camera);
 int kifs_multi_set_options(kifs_multi* m, const KifsOptionsUniform* options);
 int kifs_multi_set_iters(kifs_multi* m, int sdf_iters, int normal_iters, int fold_iters);
 int kifs_multi_set_extensions(kifs_multi* m, const KifsExtensions* ext);
+/* Shares of the devices, one integer per device in the order they were listed (NULL: equal). */
+int kifs_multi_set_weights(kifs_multi* m, const int* weights);
 /* `out_rgba8`: host memory or device memory of the root device; full frame, `pitch_bytes`
- * per row.  Returns when the frame is complete. */
+ * per row.  Returns when the frame is complete.  KIFS_ERR_COMM: a peer copy failed. */
 int kifs_multi_render(kifs_multi* m, uint8_t* out_rgba8, size_t pitch_bytes, int encode);
-/* Band i of the last configured screen: device ordinal and rows [y0, y1). */
-int kifs_multi_band(kifs_multi* m, int i, int* device_ordinal, int* y0, int* y1);
-/* Kernel time of band i in the last kifs_multi_render, ms (load balance across bands). */
-double kifs_multi_band_ms(kifs_multi* m, int i);
+/* Shard i of the configured screen: device ordinal, number of stripes, total rows. */
+int kifs_multi_shard(kifs_multi* m, int i, int* device_ordinal, int* n_stripes, int* rows);
+/* Kernel time of shard i in the last kifs_multi_render, ms (load balance across devices). */
+double kifs_multi_shard_ms(kifs_multi* m, int i);
 
 /* Device time of the most recent kifs_render on this context in ms (HIP events
  * on the launch stream), or a negative value if none completed. */

@@ -91,8 +91,9 @@ SIGNATURES = {
     "kifs_multi_set_options": (C.c_int, [_ctx, _P(OptionsUniform)]),
     "kifs_multi_set_iters": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
     "kifs_multi_render": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_int]),
-    "kifs_multi_band": (C.c_int, [_ctx, C.c_int, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
-    "kifs_multi_band_ms": (C.c_double, [_ctx, C.c_int]),
+    "kifs_multi_set_weights": (C.c_int, [_ctx, _P(C.c_int)]),
+    "kifs_multi_shard": (C.c_int, [_ctx, C.c_int, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
+    "kifs_multi_shard_ms": (C.c_double, [_ctx, C.c_int]),
     "kifs_last_kernel_ms": (C.c_double, [_ctx]),
     "kifs_synchronize": (C.c_int, [_ctx]),
     "kifs_set_profiling": (C.c_int, [_ctx, C.c_int]),

@@ -1118,13 +1118,50 @@ int kifs_eval_math(kifs_ctx* c, int fn, const float* in, float param, float* out
 struct kifs_multi {
     std::vector<kifs_ctx*> ctx;
     std::vector<int> dev;
-    std::vector<uint8_t*> band;        // per-device band buffer (non-root)
-    std::vector<size_t> band_bytes;
-    std::vector<hipEvent_t> ev0, ev1;  // kernel start/stop on each device's stream
-    std::vector<double> band_ms;
-    uint8_t* root_frame = nullptr;     // staging frame on the root when the destination is host memory
+    std::vector<int> weight;               // share of each device (kifs_shard_stripes weights)
+    std::vector<std::vector<int>> stripes; // the shard of each device for the current frame height
+    std::vector<int> rows;
+    int stripes_height = -1;
+    std::vector<uint8_t*> shard;           // per-device packed shard buffer (on that device; non-root)
+    std::vector<size_t> shard_bytes;
+    std::vector<uint8_t*> recv;            // the same shards after the peer copy (on the root device)
+    std::vector<size_t> recv_bytes;
+    std::vector<hipEvent_t> ev0, ev1;      // kernel start/stop on each device's stream
+    std::vector<double> shard_ms;
+    uint8_t* root_frame = nullptr;         // staging frame on the root when the destination is host memory
     size_t root_frame_bytes = 0;
 };
+
+namespace {
+
+bool grow(uint8_t*& buf, size_t& have, size_t need, const char* what) {
+    if (need <= have) return true;
+    if (buf) (void)hipFree(buf);
+    buf = nullptr;
+    have = 0;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&buf), need), what)) return false;
+    have = need;
+    return true;
+}
+
+// (Re)deal the frame's stripes to the devices.
+int multi_partition(kifs_multi* m, int h) {
+    if (m->stripes_height == h) return KIFS_OK;
+    const int n = int(m->ctx.size());
+    const int all = (h + KIFS_STRIPE_ROWS - 1) / KIFS_STRIPE_ROWS;
+    for (int i = 0; i < n; ++i) {
+        m->stripes[size_t(i)].assign(size_t(all), 0);
+        int count = 0, rows = 0;
+        int st = kifs_shard_stripes(h, n, m->weight.data(), i, m->stripes[size_t(i)].data(), all, &count, &rows);
+        if (st != KIFS_OK) return st;
+        m->stripes[size_t(i)].resize(size_t(count));
+        m->rows[size_t(i)] = rows;
+    }
+    m->stripes_height = h;
+    return KIFS_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1134,13 +1171,15 @@ void kifs_multi_destroy(kifs_multi* m) {
         if (!m->ctx[i]) continue;
         DeviceGuard g(m->dev[i]);
         (void)hipStreamSynchronize(m->ctx[i]->stream);
-        if (i < m->band.size() && m->band[i]) (void)hipFree(m->band[i]);
+        if (i < m->shard.size() && m->shard[i]) (void)hipFree(m->shard[i]);
         if (i < m->ev0.size() && m->ev0[i]) (void)hipEventDestroy(m->ev0[i]);
         if (i < m->ev1.size() && m->ev1[i]) (void)hipEventDestroy(m->ev1[i]);
     }
-    if (m->root_frame) {
+    if (!m->dev.empty()) {
         DeviceGuard g(m->dev[0]);
-        (void)hipFree(m->root_frame);
+        for (uint8_t* r : m->recv)
+            if (r) (void)hipFree(r);
+        if (m->root_frame) (void)hipFree(m->root_frame);
     }
     for (kifs_ctx* c : m->ctx) kifs_destroy(c);
     delete m;
@@ -1155,11 +1194,17 @@ kifs_multi* kifs_multi_create(const int* devices, int n, int* status) {
     if (!devices || n <= 0 || n > 64) return fail(KIFS_ERR_BAD_ARG, nullptr);
     kifs_multi* m = new (std::nothrow) kifs_multi();
     if (!m) return fail(KIFS_ERR_DEVICE_INIT, nullptr);
-    m->band.assign(size_t(n), nullptr);
-    m->band_bytes.assign(size_t(n), 0);
-    m->ev0.assign(size_t(n), nullptr);
-    m->ev1.assign(size_t(n), nullptr);
-    m->band_ms.assign(size_t(n), -1.0);
+    const size_t N = size_t(n);
+    m->weight.assign(N, 1);
+    m->stripes.assign(N, {});
+    m->rows.assign(N, 0);
+    m->shard.assign(N, nullptr);
+    m->shard_bytes.assign(N, 0);
+    m->recv.assign(N, nullptr);
+    m->recv_bytes.assign(N, 0);
+    m->ev0.assign(N, nullptr);
+    m->ev1.assign(N, nullptr);
+    m->shard_ms.assign(N, -1.0);
     for (int i = 0; i < n; ++i) {
         int st = KIFS_OK;
         kifs_ctx* c = kifs_create(devices[i], &st);
@@ -1194,18 +1239,36 @@ int kifs_multi_set_options(kifs_multi* m, const KifsOptionsUniform* o) { KIFS_MU
 int kifs_multi_set_iters(kifs_multi* m, int a, int b, int f) { KIFS_MULTI_FORWARD(kifs_set_iters(c, a, b, f)) }
 int kifs_multi_set_extensions(kifs_multi* m, const KifsExtensions* e) { KIFS_MULTI_FORWARD(kifs_set_extensions(c, e)) }
 
-int kifs_multi_band(kifs_multi* m, int i, int* device, int* y0, int* y1) {
-    if (!m || i < 0 || size_t(i) >= m->ctx.size() || !y0 || !y1) return KIFS_ERR_BAD_ARG;
+int kifs_multi_set_weights(kifs_multi* m, const int* weights) {
+    if (!m) return KIFS_ERR_BAD_ARG;
+    long long total = 0;
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        const int w = weights ? weights[i] : 1;
+        if (w < 0 || w > (1 << 20)) return KIFS_ERR_BAD_ARG;
+        total += w;
+    }
+    if (total <= 0) return KIFS_ERR_BAD_ARG;
+    for (size_t i = 0; i < m->ctx.size(); ++i) m->weight[i] = weights ? weights[i] : 1;
+    m->stripes_height = -1;
+    return KIFS_OK;
+}
+
+int kifs_multi_shard(kifs_multi* m, int i, int* device, int* n_stripes, int* rows) {
+    if (!m || i < 0 || size_t(i) >= m->ctx.size()) return KIFS_ERR_BAD_ARG;
     int w, h;
     if (!m->ctx[0]->have_screen) return KIFS_ERR_UNCONFIGURED;
     int st = frame_dims(m->ctx[0], &w, &h);
     if (st != KIFS_OK) return st;
+    st = multi_partition(m, h);
+    if (st != KIFS_OK) return st;
     if (device) *device = m->dev[size_t(i)];
-    return kifs_band_range(h, i, int(m->ctx.size()), y0, y1);
+    if (n_stripes) *n_stripes = int(m->stripes[size_t(i)].size());
+    if (rows) *rows = m->rows[size_t(i)];
+    return KIFS_OK;
 }
 
-double kifs_multi_band_ms(kifs_multi* m, int i) {
-    return (m && i >= 0 && size_t(i) < m->band_ms.size()) ? m->band_ms[size_t(i)] : -1.0;
+double kifs_multi_shard_ms(kifs_multi* m, int i) {
+    return (m && i >= 0 && size_t(i) < m->shard_ms.size()) ? m->shard_ms[size_t(i)] : -1.0;
 }
 
 int kifs_multi_render(kifs_multi* m, uint8_t* out, size_t pitch, int encode) {
@@ -1217,8 +1280,10 @@ int kifs_multi_render(kifs_multi* m, uint8_t* out, size_t pitch, int encode) {
     if (st != KIFS_OK) return st;
     const size_t row_bytes = size_t(w) * 4;
     if (pitch < row_bytes || (pitch & 3u)) return KIFS_ERR_BAD_SIZE;
+    st = multi_partition(m, h);
+    if (st != KIFS_OK) return st;
     const int n = int(m->ctx.size());
-    // the frame the bands are collected into: the caller's buffer if it is root-device memory
+    // the frame the shards are collected into: the caller's buffer if it is root-device memory
     uint8_t* frame = out;
     size_t fpitch = pitch;
     bool host_dst;
@@ -1226,67 +1291,49 @@ int kifs_multi_render(kifs_multi* m, uint8_t* out, size_t pitch, int encode) {
         DeviceGuard g(m->dev[0]);
         host_dst = !is_device_pointer(out);
         if (host_dst) {
-            const size_t need = row_bytes * size_t(h);
-            if (need > m->root_frame_bytes) {
-                if (m->root_frame) (void)hipFree(m->root_frame);
-                m->root_frame = nullptr;
-                m->root_frame_bytes = 0;
-                if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&m->root_frame), need), "hipMalloc(multi frame)"))
-                    return KIFS_ERR_RUNTIME;
-                m->root_frame_bytes = need;
-            }
+            if (!grow(m->root_frame, m->root_frame_bytes, row_bytes * size_t(h), "hipMalloc(multi frame)")) return KIFS_ERR_RUNTIME;
             frame = m->root_frame;
             fpitch = row_bytes;
         }
     }
-    // 1. launch every band on its own device
+    // 1. every device renders its shard: the root straight into the frame, the others into a packed buffer
     for (int i = 0; i < n; ++i) {
-        int y0, y1;
-        kifs_band_range(h, i, n, &y0, &y1);
         kifs_ctx* c = m->ctx[size_t(i)];
         DeviceGuard g(m->dev[size_t(i)]);
-        uint8_t* dst;
-        size_t dpitch;
-        if (i == 0) {
-            dst = frame + size_t(y0) * fpitch;
-            dpitch = fpitch;
-        } else {
-            const size_t need = row_bytes * size_t(y1 - y0);
-            if (need > m->band_bytes[size_t(i)]) {
-                if (m->band[size_t(i)]) (void)hipFree(m->band[size_t(i)]);
-                m->band[size_t(i)] = nullptr;
-                m->band_bytes[size_t(i)] = 0;
-                if (need && !hip_ok(hipMalloc(reinterpret_cast<void**>(&m->band[size_t(i)]), need), "hipMalloc(band)"))
-                    return KIFS_ERR_RUNTIME;
-                m->band_bytes[size_t(i)] = need;
-            }
-            dst = m->band[size_t(i)];
+        const std::vector<int>& stripes = m->stripes[size_t(i)];
+        uint8_t* dst = frame;
+        size_t dpitch = fpitch;
+        if (i != 0) {
+            if (!grow(m->shard[size_t(i)], m->shard_bytes[size_t(i)], row_bytes * size_t(m->rows[size_t(i)]), "hipMalloc(shard)"))
+                return KIFS_ERR_RUNTIME;
+            dst = m->shard[size_t(i)];
             dpitch = row_bytes;
         }
         if (hipEventRecord(m->ev0[size_t(i)], c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
-        if (y1 > y0) {
-            st = enqueue(c, c->stream, dst, dpitch, y0, y1, encode);
+        if (!stripes.empty()) {
+            st = enqueue_batch(c, c->stream, 1, nullptr, &dst, dpitch, 0, h, encode, stripes.data(), int(stripes.size()),
+                               i == 0 ? 1 : 0);
             if (st != KIFS_OK) return st;
         }
         if (hipEventRecord(m->ev1[size_t(i)], c->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
     }
-    // 2. the root pulls each finished band into its frame over xGMI, in band order
+    // 2. the root pulls each finished shard over xGMI and moves its stripes to their frame rows
     {
         DeviceGuard g(m->dev[0]);
         for (int i = 1; i < n; ++i) {
-            int y0, y1;
-            kifs_band_range(h, i, n, &y0, &y1);
-            if (y1 <= y0) continue;
+            const std::vector<int>& stripes = m->stripes[size_t(i)];
+            if (stripes.empty()) continue;
+            const size_t bytes = row_bytes * size_t(m->rows[size_t(i)]);
+            if (!grow(m->recv[size_t(i)], m->recv_bytes[size_t(i)], bytes, "hipMalloc(received shard)")) return KIFS_ERR_RUNTIME;
             if (hipStreamWaitEvent(root->stream, m->ev1[size_t(i)], 0) != hipSuccess) return KIFS_ERR_RUNTIME;
-            hipError_t e;
-            if (fpitch == row_bytes) {
-                e = hipMemcpyPeerAsync(frame + size_t(y0) * fpitch, m->dev[0], m->band[size_t(i)],
-                                       m->dev[size_t(i)], row_bytes * size_t(y1 - y0), root->stream);
-            } else {  // padded destination rows: 2-D copy (unified addressing resolves the peer)
-                e = hipMemcpy2DAsync(frame + size_t(y0) * fpitch, fpitch, m->band[size_t(i)], row_bytes,
-                                     row_bytes, size_t(y1 - y0), hipMemcpyDeviceToDevice, root->stream);
-            }
-            if (!hip_ok(e, "peer copy of a band")) return KIFS_ERR_COMM;
+            if (!hip_ok(hipMemcpyPeerAsync(m->recv[size_t(i)], m->dev[0], m->shard[size_t(i)], m->dev[size_t(i)], bytes,
+                                           root->stream), "peer copy of a shard"))
+                return KIFS_ERR_COMM;
+            const RowTable* rows = row_table(root, stripes.data(), int(stripes.size()), h);
+            if (!rows) return KIFS_ERR_RUNTIME;
+            if (!hip_ok(kifs::launch_unpack_stripes(frame, fpitch, 0, m->recv[size_t(i)], row_bytes, 0, rows->d_rows,
+                                                    int(stripes.size()), 1, w, h, root->stream), "unpack_stripes_kernel launch"))
+                return KIFS_ERR_RUNTIME;
         }
         if (host_dst &&
             !hip_ok(hipMemcpy2DAsync(out, pitch, frame, fpitch, row_bytes, size_t(h), hipMemcpyDeviceToHost,
@@ -1298,7 +1345,7 @@ int kifs_multi_render(kifs_multi* m, uint8_t* out, size_t pitch, int encode) {
         DeviceGuard g(m->dev[size_t(i)]);
         if (hipStreamSynchronize(m->ctx[size_t(i)]->stream) != hipSuccess) return KIFS_ERR_RUNTIME;
         float ms = 0.0f;
-        m->band_ms[size_t(i)] =
+        m->shard_ms[size_t(i)] =
             hipEventElapsedTime(&ms, m->ev0[size_t(i)], m->ev1[size_t(i)]) == hipSuccess ? double(ms) : -1.0;
     }
     return KIFS_OK;

@@ -431,8 +431,8 @@ class GraphicState:
 
 
 class MultiGraphicState:
-    """Single-process multi-GPU renderer over kifs_multi_* (one context per device, bands
-    collected on the first device by peer-to-peer copies)."""
+    """Single-process multi-GPU renderer over kifs_multi_* (one context per device, 8-row stripes
+    dealt to the devices, shards collected on the first device by peer-to-peer copies)."""
 
     def __init__(self, devices, screen_data: ScreenData, camera_data: CameraData = None,
                  gui_data: GuiData = None, iters=(100, 10, 10)):
@@ -467,12 +467,18 @@ class MultiGraphicState:
         check(lib.kifs_multi_render(self._m, ptr, pitch_bytes or w * 4, encode), "multi render")
         return out
 
-    def bands(self):
+    def set_weights(self, weights=None):
+        """Shares of the devices (one integer each, None = equal)."""
+        arr = None if weights is None else (C.c_int * len(self.devices))(*[int(w) for w in weights])
+        check(lib.kifs_multi_set_weights(self._m, arr), "multi set_weights")
+
+    def shards(self):
+        """[(device, n_stripes, rows, kernel ms of the last render)] per listed device."""
         res = []
         for i in range(len(self.devices)):
-            d, y0, y1 = C.c_int(), C.c_int(), C.c_int()
-            check(lib.kifs_multi_band(self._m, i, C.byref(d), C.byref(y0), C.byref(y1)))
-            res.append((d.value, y0.value, y1.value, float(lib.kifs_multi_band_ms(self._m, i))))
+            d, n, rows = C.c_int(), C.c_int(), C.c_int()
+            check(lib.kifs_multi_shard(self._m, i, C.byref(d), C.byref(n), C.byref(rows)))
+            res.append((d.value, n.value, rows.value, float(lib.kifs_multi_shard_ms(self._m, i))))
         return res
 
     def close(self):

@@ -171,8 +171,9 @@ def test_orbit_frames_match_oracle(gs, kifs, oracle):
 
 
 def test_single_process_multi_device_render(kifs, oracle):
-    """kifs_multi_*: one context per listed device, bands collected on the root by peer copies.
-    On a one-GPU box the device is listed several times; the frame must equal the oracle's."""
+    """kifs_multi_*: one context per listed device, stripe shards collected on the root by peer copies
+    and unpacked.  On a one-GPU box the device is listed several times; the frame must equal the
+    oracle's, with equal and with unequal shares."""
     import torch
     screen, cam = kifs.ScreenData(200, 135), kifs.CameraData(origin_distance=3.2, phi=0.4)
     gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2))
@@ -187,10 +188,34 @@ def test_single_process_multi_device_render(kifs, oracle):
             mg.render(out=padded, pitch_bytes=200 * 4 + 64)             # padded rows
             got = padded.cpu().numpy()
             assert (got[:, :800].reshape(135, 200, 4) == want).all() and (got[:, 800:] == 7).all()
-            bands = mg.bands()
-            assert bands[0][1] == 0 and bands[-1][2] == 135 and all(b[3] > 0 for b in bands)
+            shards = mg.shards()
+            assert sum(sh[1] for sh in shards) == 17 and sum(sh[2] for sh in shards) == 135  # 17 stripes, 135 rows
+            assert all(sh[3] >= 0 for sh in shards) and shards[0][3] > 0
+            if n > 1:
+                mg.set_weights([3] + [1] * (n - 1))
+                assert (mg.render() == want).all(), (n, "weighted")
+                assert mg.shards()[0][1] > mg.shards()[1][1]
+                with pytest.raises(kifs.KifsError):
+                    mg.set_weights([0] * n)
     with pytest.raises(kifs.KifsError):
         kifs.MultiGraphicState([0, 4096], screen)
+
+
+def test_multi_device_render_on_distinct_devices(kifs, oracle):
+    """The same on as many DISTINCT devices as the box has (skipped on a one-GPU box): real peer copies
+    over xGMI, and every device's shard must report its kernel time."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs at least two GPUs")
+    screen, cam = kifs.ScreenData(640, 360), kifs.CameraData(origin_distance=3.0, phi=0.4)
+    gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2))
+    want = oracle_frame(oracle, kifs, screen, cam, gui, (12, 10, 10))
+    with kifs.MultiGraphicState(list(range(n)), screen, cam, gui, iters=(12, 10, 10)) as mg:
+        assert (mg.render() == want).all()
+        shards = mg.shards()
+        assert [sh[0] for sh in shards] == list(range(n)) and all(sh[3] > 0 for sh in shards)
+        assert sum(sh[2] for sh in shards) == 360
 
 
 def test_tile_order_feedback_never_changes_pixels(gs, kifs, oracle):
