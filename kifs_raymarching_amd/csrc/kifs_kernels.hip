@@ -412,12 +412,6 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     const int tile_y = int(tile >> 16) * TILE_H;         // row offset within the launch's rows
     const int frame_y = tile_frame_row(P, tile >> 16);   // the tile's first frame row
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (srgb) {
-#pragma unroll
-        for (uint32_t i = 0; i < 256; i += 64) s_srgb[i + lane] = P.srgb_table[i + lane];
-    }
-#pragma unroll
-    for (int r = 0; r < TILE_H; r += 2) s_tile[r + int(lane >> 5)][lane & 31u] = P.background_rgba;
 
     // ---- round 0's queue: the rays that survive the culls, block by block
     uint32_t n = 0;  // wave-uniform throughout (sums of ballot counts)
@@ -437,6 +431,28 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
         }
         n += uint32_t(__builtin_popcountll(m));
     }
+    if (n == 0u) {
+        // Nine tiles in ten of a 1080p frame: no ray survives the culls.  Such a wave writes the
+        // background straight from registers -- no LDS, no table -- and is gone.
+#pragma unroll
+        for (int r = 0; r < TILE_H; r += 2) {
+            const int sx = int(lane & 31u), sy = r + int(lane >> 5);
+            const int ox = tile_x + sx;
+            if (ox < P.width && (frame_y + sy) < P.y1)
+                P.out[out_row(P, frame_y + sy, tile_y + sy) * P.pitch_words + uint32_t(ox)] = P.background_rgba;
+        }
+        if (feedback && lane == 0 && batch == 1) {  // (in a batch the sort has cleared the table: atomicMax with 0 is a no-op)
+            const uint32_t tiles_x = uint32_t(P.width + TILE_W - 1) / TILE_W;
+            P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)] = 0u;
+        }
+        return;
+    }
+    if (srgb) {
+#pragma unroll
+        for (uint32_t i = 0; i < 256; i += 64) s_srgb[i + lane] = P.srgb_table[i + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < TILE_H; r += 2) s_tile[r + int(lane >> 5)][lane & 31u] = P.background_rgba;
     __syncthreads();  // one wave: orders the LDS traffic, costs nothing
 
     // ---- rounds
@@ -629,7 +645,8 @@ static hipError_t launch_variant(const BatchParams& B, hipStream_t stream) {
         }
     }
     if (P.round_steps > 0 && P.group_tiles == 0) {  // the throughput path, one wave per tile
-        hipLaunchKernelGGL((render_wave_kernel<GROUP, PRIM>), dim3(P.tile_count * uint32_t(B.count)), dim3(64), 0, stream, B);
+        hipLaunchKernelGGL((render_wave_kernel<GROUP, PRIM>), dim3(P.tile_count * uint32_t(B.count)), dim3(64),
+                           residency_pad_bytes(0), stream, B);  // (the pad: KIFS_LDS_PAD under KIFS_TUNING, else 0)
         return hipGetLastError();
     }
     if (P.round_steps > 0) {  // the throughput path: rays re-queued, one or two tiles per workgroup
