@@ -1,5 +1,6 @@
 // The asm statement of julia_fast_march (kifs_scene.hpp), included once per variant with
-// KIFS_JULIA_DIVSQRT / KIFS_JULIA_DIVSQRT_OUT_OF_LINE defined by the includer.  See the
+// KIFS_JULIA_DIVSQRT / KIFS_JULIA_DIVSQRT_OUT_OF_LINE, KIFS_FAST_TRIP / KIFS_JULIA_PROLOGUE / KIFS_JULIA_C_OPERANDS
+// defined by the includer.  See the
 // register map and the description there.
     asm volatile(
         "s_setprio 3\n"   // after the culls only rays that reach the fractal get here: issue them first
@@ -24,14 +25,7 @@
         "s_mov_b64 s[78:79], vcc\n"                           // lanes outside the sphere (usually none)
         "s_andn2_b64 exec, exec, vcc\n"                       // lanes inside run the orbit
         "s_cbranch_execz 40f\n"
-        "v_pk_mul_f32 v[46:47], v[32:33], s[90:91]\n"         // T = [2 x_0, 1]
-        "v_mov_b64 v[40:41], v[30:31]\n"                  // YZ = [y_0, z_0]
-        "v_mov_b64 v[42:43], v[38:39]\n"                      // WD = [0.1, 1]
-        "v_pk_mul_f32 v[48:49], v[40:41], v[40:41]\n"         // squares of q_0 -> Q = [|q_0|^2, x_1]
-        "v_pk_add_f32 v[50:51], v[48:49], v[48:49] op_sel:[0,1] op_sel_hi:[0,1]\n"
-        "v_pk_fma_f32 v[48:49], v[42:43], v[42:43], v[50:51] op_sel_hi:[0,0,1]\n"
-        "v_pk_fma_f32 v[44:45], v[32:33], v[32:33], v[48:49] op_sel_hi:[0,0,1] neg_hi:[0,0,1]\n"
-        "v_pk_add_f32 v[44:45], v[44:45], %[c0x]\n"
+        KIFS_JULIA_PROLOGUE
         "s_mov_b64 s[86:87], exec\n"
         "s_mov_b32 s96, %[blocks]\n"
         "s_cmp_lg_u32 %[rem], 0\n"
@@ -161,8 +155,8 @@
         : "+{v[30:31]}"(pyz), "+{v[32:33]}"(px1), "+{v[34:35]}"(tdx), [trips] "+s"(trips),
           [hit] "+s"(hit_mask), [live] "=&s"(live_out), [nout] "+s"(outside_steps)
         : "{v[36:37]}"(dyz), "{v[38:39]}"(w0), "{v59}"(c1), [oyz] "s"(oyz), [ox] "s"(P.origin.x),
-          [eps] "s"(P.epsilon), [maxd] "s"(P.max_distance), [bound] "s"(P.bound_n2), [cyz] "s"(cyz),
-          [cw0] "s"(cw0), [c0x] "s"(c0x), [maxit] "s"(P.max_iterations), [limit] "s"(limit), [blocks] "s"(P.orbit_blocks),
+          [eps] "s"(P.epsilon), [maxd] "s"(P.max_distance), [bound] "s"(P.bound_n2), KIFS_JULIA_C_OPERANDS,
+          [maxit] "s"(P.max_iterations), [limit] "s"(limit), [blocks] "s"(P.orbit_blocks),
           [rem] "s"(P.orbit_rem), [lanes] "s"(lanes), [cull] "s"(P.cull_n2), [cullv] "v"(P.cull_n2)
         : "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
           "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62", "v63", "s84",

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
                                 : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y), fmaf_(t, dir.z, P.origin.z)};
             bool hit = false, marching = have;
             int wave_trips = trips;
-            march_round<GROUP, PRIM>(P, dir, t, p, hit, marching, wave_trips, limit);
+            march_round<GROUP, PRIM, true>(P, dir, t, p, hit, marching, wave_trips, limit);  // the orbit in its scalar form
             __builtin_amdgcn_s_setprio(0);
             const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
             const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);

@@ -483,7 +483,15 @@ KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit, Sdf
 //            v[38:39] [0.1, 1]  v[40:51] orbit (see julia_interior)  v52-v63 scratch, v59 = c1
 //            s[84:85] caller exec  s[86:87] live lanes of the step  s[88:91] [2,4],[2,1]
 //            s92 mantissa mask  s93/s94 class masks  s96/s97 trip counters  s[80:83] compare masks
-#define KIFS_FAST_TRIP                                                                      \
+// One orbit trip, two forms of the same operations (results bit for bit the same):
+//  * PACKED: 8 v_pk_*_f32 + v_cmpx -- the fewest instructions, for a wave alone on its SIMD (a lone wave
+//    issues one instruction per ~5 cycles whatever it is): the latency path.
+//  * SCALAR: 13 plain f32 operations + v_cmpx -- the fewest VALU CYCLES, for SIMDs with several busy
+//    waves, where the vector pipe is the limit: a wave64 v_fma_f32 occupies it for 2.25 cycles, a packed
+//    one for 4.3 (tools/microbench/valu_rate.hip), so the packed trip costs 38 cycles and this one 33.
+//    Same registers, the pairs of the packed form taken apart: v40 y  v41 z  v42 w  v43 dq  v44 |q|^2
+//    v45 x_next  v46 2x  v47 4|q_prev|^2  v48-v50 scratch.
+#define KIFS_FAST_TRIP_PACKED                                                               \
     "v_pk_fma_f32 v[40:41], v[46:47], v[40:41], %[cyz] op_sel_hi:[0,1,1]\n"                   \
     "v_pk_fma_f32 v[42:43], v[46:47], v[42:43], %[cw0]\n"                                     \
     "v_pk_mul_f32 v[46:47], v[44:45], s[88:89] op_sel:[1,0] op_sel_hi:[0,1]\n"                \
@@ -493,6 +501,43 @@ KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit, Sdf
     "v_pk_fma_f32 v[44:45], v[44:45], v[44:45], v[48:49] op_sel:[1,1,0] op_sel_hi:[1,1,1] neg_hi:[0,0,1]\n" \
     "v_pk_add_f32 v[44:45], v[44:45], %[c0x]\n"                                               \
     "v_cmpx_nlt_f32 vcc, %[maxd], v44\n" /* exec &= !(|q|^2 > max_distance): escaped lanes freeze */
+#define KIFS_FAST_TRIP_SCALAR                                                               \
+    "v_fma_f32 v40, v46, v40, %[cy]\n"        /* y' = fma(2x, y, c.y) */                      \
+    "v_fma_f32 v41, v46, v41, %[cz]\n"                                                        \
+    "v_fma_f32 v42, v46, v42, %[cw]\n"                                                        \
+    "v_fma_f32 v43, v47, v43, 0\n"            /* dq = fma(4|q_prev|^2, dq, 0) (one trip late) */ \
+    "v_mul_f32_e32 v46, 2.0, v45\n"           /* 2 x_next */                                  \
+    "v_mul_f32_e32 v47, 4.0, v44\n"           /* 4 |q|^2 */                                   \
+    "v_mul_f32_e32 v48, v40, v40\n"                                                           \
+    "v_mul_f32_e32 v49, v41, v41\n"                                                           \
+    "v_add_f32_e32 v50, v48, v49\n"           /* s = y*y + z*z */                             \
+    "v_fma_f32 v48, v42, v42, v50\n"          /* d = fma(w, w, s) */                          \
+    "v_fma_f32 v44, v45, v45, v48\n"          /* |q|^2 = fma(x, x, d) */                      \
+    "v_fma_f32 v45, v45, v45, -v48\n"         /* fma(x, x, -d) */                             \
+    "v_add_f32_e32 v45, %[cx], v45\n"         /* + c.x: the x after next */                   \
+    "v_cmpx_nlt_f32 vcc, %[maxd], v44\n"
+// the squares of q_0 in front of the first trip, same two forms
+#define KIFS_JULIA_PROLOGUE_PACKED                                                          \
+    "v_pk_mul_f32 v[46:47], v[32:33], s[90:91]\n"         /* T = [2 x_0, 1] */               \
+    "v_mov_b64 v[40:41], v[30:31]\n"                      /* YZ = [y_0, z_0] */              \
+    "v_mov_b64 v[42:43], v[38:39]\n"                      /* WD = [0.1, 1] */                \
+    "v_pk_mul_f32 v[48:49], v[40:41], v[40:41]\n"         /* squares of q_0 -> Q = [|q_0|^2, x_1] */ \
+    "v_pk_add_f32 v[50:51], v[48:49], v[48:49] op_sel:[0,1] op_sel_hi:[0,1]\n"               \
+    "v_pk_fma_f32 v[48:49], v[42:43], v[42:43], v[50:51] op_sel_hi:[0,0,1]\n"                \
+    "v_pk_fma_f32 v[44:45], v[32:33], v[32:33], v[48:49] op_sel_hi:[0,0,1] neg_hi:[0,0,1]\n" \
+    "v_pk_add_f32 v[44:45], v[44:45], %[c0x]\n"
+#define KIFS_JULIA_PROLOGUE_SCALAR                                                          \
+    "v_mul_f32_e32 v46, 2.0, v32\n"                                                          \
+    "v_mov_b32_e32 v47, 1.0\n"                                                               \
+    "v_mov_b64 v[40:41], v[30:31]\n"                                                         \
+    "v_mov_b64 v[42:43], v[38:39]\n"                                                         \
+    "v_mul_f32_e32 v48, v40, v40\n"                                                          \
+    "v_mul_f32_e32 v49, v41, v41\n"                                                          \
+    "v_add_f32_e32 v50, v48, v49\n"                                                          \
+    "v_fma_f32 v48, v42, v42, v50\n"                                                         \
+    "v_fma_f32 v44, v32, v32, v48\n"                                                         \
+    "v_fma_f32 v45, v32, v32, -v48\n"                                                        \
+    "v_add_f32_e32 v45, %[cx], v45\n"
 
 // quot = |q|^2 / dqs and root = sqrt(quot), both correctly rounded, any operands: the sequences
 // hipcc emits (v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup; v_sqrt + one-ulp fixup
@@ -569,27 +614,58 @@ KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit, Sdf
     "v_cndmask_b32_e64 v60, v62, v63, s[82:83]\n" \
     "47:\n"
 
-template <bool SHORT_DIVSQRT>
+// SHORT_DIVSQRT: the launcher's choice for frames with few SDF iterations (KIFS_DIVSQRT_ORDINARY);
+// THROUGHPUT: the scalar form of the orbit trip (launches whose SIMDs hold several busy waves).
+template <bool SHORT_DIVSQRT, bool THROUGHPUT>
 KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit,
                                bool& marching, int& trips, int& outside_steps, int limit) {
     F2 pyz{p.y, p.z}, px1{p.x, 1.0f}, tdx{t, dir.x};
     const F2 dyz{dir.y, dir.z}, w0{0.1f, 1.0f};
-    const F2 oyz{P.origin.y, P.origin.z}, cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x};
+    const F2 oyz{P.origin.y, P.origin.z};
     const float c1 = -1.1514610310E-1f;  // second log coefficient, needed in a VGPR
     const unsigned long long lanes = __builtin_amdgcn_ballot_w64(marching);
     unsigned long long hit_mask = 0, live_out;
-    if constexpr (SHORT_DIVSQRT) {
+    if constexpr (THROUGHPUT) {
+#define KIFS_FAST_TRIP KIFS_FAST_TRIP_SCALAR
+#define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_SCALAR
+#define KIFS_JULIA_C_OPERANDS [cy] "s"(P.c.y), [cz] "s"(P.c.z), [cw] "s"(P.c.w), [cx] "s"(P.c.x)
+        if constexpr (SHORT_DIVSQRT) {
 #define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_ORDINARY
 #define KIFS_JULIA_DIVSQRT_OUT_OF_LINE "46:\n" KIFS_DIVSQRT_FULL "s_branch 47b\n"
 #include "kifs_julia_march_asm.hpp"
 #undef KIFS_JULIA_DIVSQRT
 #undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
-    } else {
+        } else {
 #define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_FULL
 #define KIFS_JULIA_DIVSQRT_OUT_OF_LINE
 #include "kifs_julia_march_asm.hpp"
 #undef KIFS_JULIA_DIVSQRT
 #undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
+        }
+#undef KIFS_FAST_TRIP
+#undef KIFS_JULIA_PROLOGUE
+#undef KIFS_JULIA_C_OPERANDS
+    } else {
+        const F2 cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x};
+#define KIFS_FAST_TRIP KIFS_FAST_TRIP_PACKED
+#define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_PACKED
+#define KIFS_JULIA_C_OPERANDS [cyz] "s"(cyz), [cw0] "s"(cw0), [c0x] "s"(c0x)
+        if constexpr (SHORT_DIVSQRT) {
+#define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_ORDINARY
+#define KIFS_JULIA_DIVSQRT_OUT_OF_LINE "46:\n" KIFS_DIVSQRT_FULL "s_branch 47b\n"
+#include "kifs_julia_march_asm.hpp"
+#undef KIFS_JULIA_DIVSQRT
+#undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
+        } else {
+#define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_FULL
+#define KIFS_JULIA_DIVSQRT_OUT_OF_LINE
+#include "kifs_julia_march_asm.hpp"
+#undef KIFS_JULIA_DIVSQRT
+#undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
+        }
+#undef KIFS_FAST_TRIP
+#undef KIFS_JULIA_PROLOGUE
+#undef KIFS_JULIA_C_OPERANDS
     }
     const unsigned lane = __lane_id();
     p = V3{px1.x, pyz.x, pyz.y};
@@ -613,7 +689,6 @@ KIFS_DEV bool ray_never_inside(const FrameParams& P, V3 dir) {
     return (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
 }
 
-// SHORT_DIVSQRT: the launcher's choice for frames with few SDF iterations (KIFS_DIVSQRT_ORDINARY).
 struct JuliaDiag {  // diagnostics of one wave's march (SGPRs)
     int fast_steps = 0, fast_entries = 0, general_steps = 0;
     unsigned long long fast_ticks = 0;
@@ -622,7 +697,7 @@ struct JuliaDiag {  // diagnostics of one wave's march (SGPRs)
 // The march loop proper: steps the wave's marching lanes until none is left or `trips` reaches
 // `limit` (max_iterations for a whole ray, the end of the current round when the workgroup
 // re-queues its rays).  State in, state out; i_final is the heatmap's loop counter.
-template <bool SHORT_DIVSQRT>
+template <bool SHORT_DIVSQRT, bool THROUGHPUT>
 KIFS_DEV void julia_loop(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit, bool& marching,
                          int& trips, int& i_final, int limit, JuliaDiag& diag) {
     const bool fast_ok = (P.is_heatmap == 0u) && (P.sdf_iters >= 1);  // wave-uniform
@@ -637,7 +712,7 @@ KIFS_DEV void julia_loop(const FrameParams& P, V3 dir, float& t, V3& p, bool& hi
             // compiler's SGPR handling around the asm block)
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             int outside_steps = 0;  // (a fresh SGPR for the asm block: struct members confuse the allocator)
-            julia_fast_march<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, outside_steps,
+            julia_fast_march<SHORT_DIVSQRT, THROUGHPUT>(P, dir, t, p, hit, marching, trips, outside_steps,
                                             limit < P.max_iterations ? limit : P.max_iterations);
             diag.general_steps += outside_steps;
             diag.fast_ticks += __builtin_amdgcn_s_memtime() - t0;
@@ -705,7 +780,7 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
     JuliaDiag diag;
     const bool stamp = P.counters != nullptr;
     const unsigned long long wave_t0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-    julia_loop<SHORT_DIVSQRT>(P, dir, t, p, hit, marching, trips, i_final, P.max_iterations, diag);
+    julia_loop<SHORT_DIVSQRT, false>(P, dir, t, p, hit, marching, trips, i_final, P.max_iterations, diag);
     __builtin_amdgcn_s_setprio(0);
     steps = trips;
     if (__builtin_expect(stamp, 0)) {
@@ -813,13 +888,13 @@ KIFS_DEV V3 raymarch(const FrameParams& P, V3 dir, bool valid, int& steps) {
 // One round of the workgroup's ray queue for pipeline <GROUP, PRIM>: step the wave's lanes until
 // `trips` reaches `limit`; and the colour of a hit.  (For the Julia pipeline the PRIM slot is the
 // variant of the long-ray loop, see raymarch.)
-template <int GROUP, int PRIM>
+template <int GROUP, int PRIM, bool THROUGHPUT = false>
 KIFS_DEV void march_round(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit, bool& marching,
                           int& trips, int limit) {
     int i_final = 0;  // heatmap frames do not take this path
     if constexpr (GROUP == GROUP_JULIA) {
         JuliaDiag diag;
-        julia_loop<PRIM == 1>(P, dir, t, p, hit, marching, trips, i_final, limit, diag);
+        julia_loop<PRIM == 1, THROUGHPUT>(P, dir, t, p, hit, marching, trips, i_final, limit, diag);
     } else {
         generic_loop(P, dir, t, p, hit, marching, trips, i_final, limit,
                      [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); });

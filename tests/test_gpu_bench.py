@@ -1,0 +1,64 @@
+"""bench.py's contract with the driver, on the GPU box: the one JSON line of a default-shaped run
+carries metric / value / roofline / cpu_baseline / the secondary measurements, and `--gpus 2` without a
+launcher starts its own ranks and gathers frames equal to single-GPU frames (ranks share the one GPU
+and talk over gloo: RCCL needs a GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    d = _run("--steps", "12", "--warmup", "4", "--cpu-seconds", "1")
+    assert d["metric"].startswith("Mpixels/s at 1920x1080") and d["unit"] == "Mpixels/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 4 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    cfg = d["config"]
+    assert cfg["workload"] == "cfg2_julia_1080p" and cfg["camera"].startswith("orbit")
+    assert cfg["frames_per_launch"] == 32 and cfg["frames_per_step"] == 32
+    assert d["value"] > 1000.0  # the north star's 1 Gpixel/s
+    assert abs(d["value"] - 32 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert r["kernel"] == "render_wave_kernel" and r["launches_timed"] >= 2
+    assert 0 < r["kernel_ms"] <= d["ms_per_step"] * 1.02
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert r["algorithmic_bytes_per_launch"] == 32 * 1920 * 1080 * 4
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    assert r["traffic_source"] == "profiles/pmc_traffic.json"
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mpixels/s" and c["cores"] >= 1 and c["value"] > 0
+    sec = d["secondary"]
+    assert set(sec) == {"lone_frame", "orbit_x8", "fixed_camera"}
+    assert sec["lone_frame"]["frames_per_launch"] == 1 and sec["orbit_x8"]["frames_per_launch"] == 8
+    assert all(v["mpix_s"] > 0 and v["kernel_ms"] > 0 for v in sec.values())
+    assert d["per_rank_kernel_ms"] == [pytest.approx(r["kernel_ms"], rel=1e-3)]
+
+
+def test_two_ranks_are_started_by_bench_itself_and_gather_exact_frames():
+    d = _run("--gpus", "2", "--backend", "gloo", "--share-device", "--check", "--steps", "4", "--warmup", "2",
+             "--cpu-seconds", "0", "--frames-per-launch", "4")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["gathered_frame_equals_single_gpu_frame"] is True
+    cfg = d["config"]
+    assert cfg["frames_per_step"] == 8 and "8-row stripes" in cfg["parallelism"] and "RCCL" in cfg["parallelism"]
+    assert cfg["root_weight"] >= 1 and sum(cfg["rows_per_rank"]) == 1080
+    assert set(cfg["root_weight_calibration"]) == {"render_ms_equal_shares", "gather_ms_equal_shares"}
+    assert len(d["per_rank_kernel_ms"]) == 2 and all(x > 0 for x in d["per_rank_kernel_ms"])
+    assert "frame_parallel" in d["secondary"] and "NOT the north star" in d["secondary"]["frame_parallel"]["note"]
