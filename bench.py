@@ -390,6 +390,7 @@ def main():
         t = torch.tensor([w], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
         dist.broadcast(t, src=0)
         del sf
+        torch.cuda.empty_cache()  # the calibration's frame buffers must not sit beside the run's
         return int(t.item()), {"render_ms_equal_shares": round(t_render * 1e3, 4),
                                "gather_ms_equal_shares": round(t_gather * 1e3, 4)}
 
@@ -398,6 +399,8 @@ def main():
     root_weight, calibration = 1, None
     if sharded:
         frames_per_step = B * world if args.scaling == "weak" else B
+        # rank 0 keeps two buffers of the step's finished frames: at most 24 GB of them (8K frames: 90)
+        frames_per_step = max(1, min(frames_per_step, int(24e9 // (2 * 4 * W * H))))
         if args.shard == "stripes":
             if args.root_weight == "auto":
                 root_weight, calibration = calibrate_root_weight(frames_per_step)
