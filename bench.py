@@ -4,7 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 A "step" is one pass of the render path over one batch of synthetic input: the next
-`--frames-per-launch` (default 32) frames of the workload's ORBIT -- one camera pose and one
+`--frames-per-launch` (default 48) frames of the workload's ORBIT -- one camera pose and one
 destination per frame, packed by the host camera model exactly as the reference does per frame
 (render.rs:320-345) -- rendered by one kifs_render_batch_async launch.  The default workload is
 BASELINE.json's metric configuration: 1920x1080 quaternion-Julia, 256 march steps, 12 SDF
@@ -62,8 +62,8 @@ def parse():
                     help="orbit (default): a distinct pose per frame, phi = 2*pi*frame/120 (host camera model + "
                          "64-byte uniform per frame); fixed: every frame is the workload's view")
     ap.add_argument("--orbit", action="store_true", help="same as --camera orbit (kept for older scripts)")
-    ap.add_argument("--frames-per-launch", type=int, default=32,
-                    help="frames of the sequence per launch (1..32, default 32); 1 = the lone-frame latency path")
+    ap.add_argument("--frames-per-launch", type=int, default=48,
+                    help="frames of the sequence per launch (1..64, default 48); 1 = the lone-frame latency path")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N = 1 only: launches kept in flight on separate contexts and streams")
     ap.add_argument("--shard", default="stripes", choices=["stripes", "bands", "frames"],

@@ -78,7 +78,7 @@ struct FrameParams {
 // order and differ in camera and destination (the frames of an orbit).  One frame's run time
 // is the critical path of a few long rays with most SIMDs idle; a batch fills them.  The views
 // travel in the kernel argument (56 B each: 2.1 KB with the frame constants, limit 4 KB).
-constexpr int MAX_BATCH = 32;
+constexpr int MAX_BATCH = 64;
 struct BatchView {
     V3 origin, m0, m1, m2;  // CameraUniform of this frame
     uint32_t* out;          // first row of its band

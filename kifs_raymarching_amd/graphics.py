@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 
-MAX_BATCH = 32  # KIFS_MAX_BATCH of include/kifs_hip.h
+MAX_BATCH = 64  # KIFS_MAX_BATCH of include/kifs_hip.h
 STRIPE_ROWS = 8  # KIFS_STRIPE_ROWS
 from ._lib import (CameraDataC, CameraUniform, ExtensionsC, GuiDataC, KifsError, OptionsUniform,
                    ScreenUniform, check, lib)

@@ -31,15 +31,15 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     cfg = d["config"]
     assert cfg["workload"] == "cfg2_julia_1080p" and cfg["camera"].startswith("orbit")
-    assert cfg["frames_per_launch"] == 32 and cfg["frames_per_step"] == 32
+    assert cfg["frames_per_launch"] == 48 and cfg["frames_per_step"] == 48
     assert d["value"] > 1000.0  # the north star's 1 Gpixel/s
-    assert abs(d["value"] - 32 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    assert abs(d["value"] - 48 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert r["kernel"] == "render_wave_kernel" and r["launches_timed"] >= 2
     assert 0 < r["kernel_ms"] <= d["ms_per_step"] * 1.15  # (three sampled launches of twelve: launch times vary by +-10 %)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
-    assert r["algorithmic_bytes_per_launch"] == 32 * 1920 * 1080 * 4
+    assert r["algorithmic_bytes_per_launch"] == 48 * 1920 * 1080 * 4
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
     assert r["traffic_source"] == "profiles/pmc_traffic.json"
     c = d["cpu_baseline"]

@@ -99,26 +99,26 @@ def test_headline_shards_take_the_requeuing_kernel(gs, kifs, oracle):
     assert (gathered[3].cpu().numpy() == want).all()
 
 
-def test_batch_of_32_frames(gs, kifs, oracle):
-    """KIFS_MAX_BATCH = 32 views in one launch (kernel argument of 2.1 KB)."""
+def test_batch_of_64_frames(gs, kifs, oracle):
+    """KIFS_MAX_BATCH = 64 views in one launch (kernel argument of 3.9 KB, limit 4 KB)."""
     import torch
-    assert kifs.MAX_BATCH == 32
+    assert kifs.MAX_BATCH == 64
     gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=64)
     screen = kifs.ScreenData(128, 72)
     gs.update_screen_data(screen)
     gs.update_options(gui)
     gs.set_iters(12, 10, 10)
-    cams = [kifs.CameraData(origin_distance=3.0 + 0.05 * k, phi=0.2 * k, theta=0.03 * k - 0.4) for k in range(32)]
-    outs = torch.zeros((32, 72, 128, 4), dtype=torch.uint8, device="cuda:0")
+    cams = [kifs.CameraData(origin_distance=3.0 + 0.03 * k, phi=0.2 * k, theta=0.02 * k - 0.6) for k in range(64)]
+    outs = torch.zeros((64, 72, 128, 4), dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.Stream()
-    gs.render_batch_async([outs[i] for i in range(32)], cams, stream=stream)
+    gs.render_batch_async([outs[i] for i in range(64)], cams, stream=stream)
     stream.synchronize()
     got = outs.cpu().numpy()
-    for k in (0, 7, 8, 19, 31):
+    for k in (0, 7, 8, 19, 31, 32, 47, 63):
         assert (got[k] == oracle_frame(oracle, kifs, screen, cams[k], gui, (12, 10, 10))).all(), k
-    assert len({got[k].tobytes() for k in range(32)}) == 32
+    assert len({got[k].tobytes() for k in range(64)}) == 64
     with pytest.raises(ValueError):
-        gs.render_batch_async([outs[0]] * 33, cams + cams[:1], stream=stream)
+        gs.render_batch_async([outs[0]] * 65, cams + cams[:1], stream=stream)
 
 
 def test_shard_argument_checks(gs, kifs):
@@ -143,7 +143,7 @@ def test_shard_argument_checks(gs, kifs):
     assert lib.kifs_render_shard_async(gs._ctx, None, 2, cams, ptrs, 256, None, 1, 1, 1) == 7  # NULL list
     assert call(arr(0), cams_=None) == 7          # no cameras for two frames
     assert call(arr(0), count=1, cams_=None) == 0  # one frame: the context's camera
-    assert call(arr(0), count=33) == 7
+    assert call(arr(0), count=65) == 7
     assert call(arr(0), pitch=100) == 3
     assert call(arr(0), enc=9) == 7
     un = lambda st, fp=256, sp=256: lib.kifs_unpack_shard_async(gs._ctx, None, 2, out.data_ptr(), fp, 40 * 256,

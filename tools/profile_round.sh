@@ -12,8 +12,8 @@ python bench.py > $O/cfg2_bench.json
 echo "bench default done"
 : > $O/other_workloads_bench.jsonl
 for w in cfg1_julia_256 cfg3_sierpinski_1080p cfg4_julia_4096 ref_julia_1080p n1_genjulia_1080p n2_bunny_1080p; do
-  for b in 32 8 1; do
-    python bench.py --workload $w --steps 100 --warmup 12 --cpu-seconds $([ $b = 32 ] && echo 4 || echo 0) --no-secondary --frames-per-launch $b >> $O/other_workloads_bench.jsonl
+  for b in 48 8 1; do
+    python bench.py --workload $w --steps 100 --warmup 12 --cpu-seconds $([ $b = 48 ] && echo 4 || echo 0) --no-secondary --frames-per-launch $b >> $O/other_workloads_bench.jsonl
   done
   echo "bench $w done"
 done

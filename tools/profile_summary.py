@@ -56,7 +56,7 @@ def main():
     traffic_path = ROOT / "profiles" / "pmc_traffic.json"
     traffic = json.loads(traffic_path.read_text()) if traffic_path.exists() else {}
     summary = {}
-    for tag, B in (("", 32), ("_b8", 8), ("_b1", 1)):
+    for tag, B in (("", 48), ("_b8", 8), ("_b1", 1)):
         rec = {}
         keep = []
         for kind in ("write", "fetch", "sq"):
@@ -97,7 +97,7 @@ def main():
         if rec.get("SQ_INSTS_VALU") and rec.get("SQ_THREAD_CYCLES_VALU"):
             rec["lanes_live_per_valu"] = rec["SQ_THREAD_CYCLES_VALU"] / rec["SQ_INSTS_VALU"]
         summary[f"frames_per_launch_{B}"] = rec
-        with open(dst / f"cfg2_pmc_rows{tag or '_b32'}.csv", "w", newline="") as f:
+        with open(dst / f"cfg2_pmc_rows{tag or '_b48'}.csv", "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(keep[0].keys()))
             w.writeheader()
             w.writerows(keep)

@@ -10,7 +10,7 @@ run 2 --frames-per-launch 8             # the default shape: stripes, weak scali
 run 3 --frames-per-launch 2 --no-secondary --root-weight 1
 run 4 --scaling strong --frames-per-launch 8 --no-secondary   # 8 frames per step, a quarter of each per rank
 run 2 --root-weight 3 --frames-per-launch 8 --no-secondary
-run 2 --workload cfg1_julia_256 --no-secondary   # default batch: 64 frames per step, two launches of 32
+run 2 --workload cfg1_julia_256 --no-secondary   # default batch: 96 frames per step, two launches (64 + 32)
 run 2 --shard bands --frames-per-launch 8 --no-secondary
 run 2 --shard frames --frames-per-launch 8 --no-secondary
 run 3 --shard frames --deliver root --frames-per-launch 2 --no-secondary
