@@ -283,7 +283,8 @@ int kifs_eval_points(kifs_ctx* ctx, const float* points_xyz, int n, float* sdf_o
 /* Evaluates one of the library's f32 elementary functions on the device over
  * `n` host values.  fn: 0 log, 1 log2, 2 exp2, 3 sin, 4 cos, 5 acos,
  * 6 pow(x, y) with y = `param`, 7 sRGB-encode (result as float code),
- * 8 UNORM-encode. */
+ * 8 UNORM-encode, 9 / 10 the mid-range reciprocal and square root of the generalised-Julia
+ * step (correctly rounded for 2^-60 <= x < 2^60; tests check them exhaustively). */
 int kifs_eval_math(kifs_ctx* ctx, int fn, const float* in, float param, float* out, int n);
 
 /* Diagnostics: with enable != 0, subsequent Julia renders write one record per wave into a

@@ -275,15 +275,42 @@ KIFS_DEV float acos_(float x) {
     return PIO2_F - asin_poly(x, x * x);
 }
 
-// ---- wave-guarded forms --------------------------------------------------------
-// log2_, exp2_ and acos_ start with special-case tests and (acos_) a three-way range split; compiled
-// as written each is a chain of divergent branches.  These forms return the same bits -- the same
-// operations on the same operands -- but decide once per WAVE whether any lane needs the general
-// code (NaN, infinities, zeros, denormals, out-of-range arguments: practically never inside an
-// orbit) and otherwise run straight-line code with the range split done by selects.
-KIFS_DEV float log2_wave(float x) {
-    const bool ordinary = (x >= 1.17549435e-38f) && (x <= 3.40282347e38f);  // positive normal
-    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return log2_(x);
+// ---- straight-line cores ---------------------------------------------------------
+// log2_, exp2_, acos_ and sincos_ start with special-case tests and (acos_) a three-way range split;
+// compiled as written each is a chain of divergent branches.  The *_core forms are the same
+// operations on the same operands for ORDINARY arguments -- the only ones an orbit meets in
+// practice -- with the range split done by selects, and *_ordinary says whether an argument is one.
+// A caller evaluates a whole step with the cores, then asks once per wave whether every lane's
+// arguments were ordinary, and only otherwise repeats the step with the general forms (see
+// quat_pow_shared in kifs_scene.hpp).  On any other argument a core returns garbage, never a trap.
+// Correctly rounded 1/b and sqrt(x) for MID-RANGE operands, 2^-60 <= b, x < 2^60: exactly the sequences
+// the compiler expands `/` and sqrt into (v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup; v_sqrt
+// + one-ulp fix-up with a 2^32 pre-scaling and a zero/infinity patch) minus the parts that are no-ops
+// in that range -- the scaling (exponents too close to 0 for v_div_scale to act, quotient far from the
+// denormals), the fix-up's special cases, the pre-scaling (x >= 2^-96).  Same bits, six and seven
+// instructions and two and three compares shorter.  sqrt_mid(0) = 0 as well (the candidates fail both
+// tests), which the acos tail relies on.
+KIFS_DEV bool mid_range(float x) { return (bits(x) - 0x21800000u) < (0x5d800000u - 0x21800000u); }  // [2^-60, 2^60)
+KIFS_DEV float rcp_mid(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    float e = fmaf_(-b, r, 1.0f);
+    r = fmaf_(e, r, r);
+    float q = r;  // 1 * r
+    float rem = fmaf_(-b, q, 1.0f);
+    q = fmaf_(rem, r, q);
+    rem = fmaf_(-b, q, 1.0f);
+    return fmaf_(rem, r, q);
+}
+KIFS_DEV float sqrt_mid(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = from_bits(bits(s) - 1u), sp = from_bits(bits(s) + 1u);  // candidates one ulp either side
+    const float rm = fmaf_(-sm, s, x), rp = fmaf_(-sp, s, x);
+    float r = (0.0f >= rm) ? sm : s;
+    return (0.0f < rp) ? sp : r;
+}
+
+KIFS_DEV bool log2_ordinary(float x) { return (x >= 1.17549435e-38f) && (x <= 3.40282347e38f); }  // positive normal
+KIFS_DEV float log2_core(float x) {
     int e;
     float m = log_reduce(x, e);
     float z = m * m;
@@ -297,9 +324,8 @@ KIFS_DEV float log2_wave(float x) {
     return r + float(e);
 }
 
-KIFS_DEV float exp2_wave(float x) {
-    const bool ordinary = (x <= 127.99999f) && (x >= -150.0f);  // false for NaN
-    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return exp2_(x);
+KIFS_DEV bool exp2_ordinary(float x) { return (x <= 127.99999f) && (x >= -150.0f); }  // false for NaN
+KIFS_DEV float exp2_core(float x) {
     float n = rint_(x);
     float r = x - n;
     float p = 1.535336188319500E-004f;
@@ -316,9 +342,8 @@ KIFS_DEV float exp2_wave(float x) {
     return (p * s1) * s2;
 }
 
-KIFS_DEV float acos_wave(float x) {
-    const bool ordinary = (x >= -1.0f) && (x <= 1.0f);  // false for NaN
-    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return acos_(x);
+KIFS_DEV bool acos_ordinary(float x) { return (x >= -1.0f) && (x <= 1.0f); }  // false for NaN
+KIFS_DEV float acos_core(float x) {
     const float PI_F = 3.14159265358979323846f;
     const float PIO2_F = 1.57079632679489661923f;
     const bool hi = x > 0.5f, lo = x < -0.5f;
@@ -326,18 +351,14 @@ KIFS_DEV float acos_wave(float x) {
     const float zt = 0.5f * (hi ? (1.0f - x) : (1.0f + x));
     const bool tail = hi || lo;
     const float z = tail ? zt : x * x;
-    const float a = tail ? sqrt_(zt) : x;
+    const float a = tail ? sqrt_mid(zt) : x;  // zt is 0 or in [2^-25, 0.75] for |x| <= 1
     const float r = asin_poly(a, z);
     const float two_r = 2.0f * r;
     return hi ? two_r : (lo ? PI_F - two_r : PIO2_F - r);
 }
 
-KIFS_DEV void sincos_wave(float x, float& s, float& c) {
-    const bool ordinary = abs_(x) <= 1048576.0f;  // false for NaN
-    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) {
-        sincos_(x, s, c);
-        return;
-    }
+KIFS_DEV bool sincos_ordinary(float x) { return abs_(x) <= 1048576.0f; }  // false for NaN
+KIFS_DEV void sincos_core(float x, float& s, float& c) {
     float r;
     const int q = reduce_pio2(x, r);
     const float sk = sin_kernel(r), ck = cos_kernel(r);

@@ -870,6 +870,8 @@ __global__ void eval_math_kernel(int fn, const float* __restrict__ in, float par
     case 6: r = pow_(x, param); break;
     case 7: r = float(srgb8(x, srgb_table)); break;
     case 8: r = float(unorm8(x)); break;
+    case 9: r = rcp_mid(x); break;
+    case 10: r = sqrt_mid(x); break;
     default: r = x; break;
     }
     out[i] = r;

@@ -32,26 +32,56 @@ KIFS_DEV V4 quat_sq_add(V4 q, V4 c) {
 }
 
 // quat_pow (quaternions.wgsl:57-63) with the work it shares with its callers made explicit (the
-// arithmetic contract): d = |ijk|^2, qs = |q|^2, L = log2(qs) come from the
-// caller; length(q) = sqrt(qs); the two divisions are products with correctly rounded
-// reciprocals; pow(norm, x) = exp2(x L / 2).  The elementary functions are the wave-guarded forms of
-// kifs_device_math.hpp (one ballot, then straight-line code: this is the inner loop of the slowest
-// pipeline, and a lone wave pays ~35 cycles for every taken branch).
-KIFS_DEV V4 quat_pow_shared(V4 q, float d, float qs, float L, float x) {
-    const float inv = 1.0f / sqrt_(qs);
-    const float phi = acos_wave(q.x * inv);
-    const float ninv = 1.0f / sqrt_(d);
+// arithmetic contract): d = |ijk|^2 and qs = |q|^2 come from the caller;
+// length(q) = sqrt(qs); the two divisions are products with correctly rounded reciprocals;
+// L = log2(qs) is taken once: pow(norm, x) = exp2(x L / 2), and `dq_factor` receives
+// gen_julia.wgsl:16's pow(qs, x - 1) = exp2((x - 1) L).
+// This is the inner loop of the slowest pipeline and a lone wave pays ~35 cycles for every taken
+// branch, so the step runs on the straight-line cores of kifs_device_math.hpp and checks ONCE, at
+// its end, that every lane's arguments were ordinary; a wave with a NaN, an infinity, a zero or a
+// denormal anywhere repeats the step with the general functions (same operations, same bits for
+// ordinary lanes).
+template <bool GENERAL>
+KIFS_DEV V4 quat_pow_step(V4 q, float d, float qs, float x, float& dq_factor, bool& ordinary) {
+    const float L = GENERAL ? log2_(qs) : log2_core(qs);
+    const float e1 = (x - 1.0f) * L;
+    dq_factor = GENERAL ? exp2_(e1) : exp2_core(e1);
+    const float inv = GENERAL ? 1.0f / sqrt_(qs) : rcp_mid(sqrt_mid(qs));
+    const float ca = q.x * inv;
+    const float phi = GENERAL ? acos_(ca) : acos_core(ca);
+    const float ninv = GENERAL ? 1.0f / sqrt_(d) : rcp_mid(sqrt_mid(d));
     const V3 n{q.y * ninv, q.z * ninv, q.w * ninv};
-    const float pw = exp2_wave(x * (0.5f * L));
+    const float e2 = x * (0.5f * L);
+    const float pw = GENERAL ? exp2_(e2) : exp2_core(e2);
+    const float a = x * phi;
     float cs, sn;
-    sincos_wave(x * phi, sn, cs);
+    if constexpr (GENERAL) sincos_(a, sn, cs);
+    else sincos_core(a, sn, cs);
+    // every argument a core saw was in its range: |q|^2 and |ijk|^2 mid-range (then their square roots
+    // are too, and L is finite), both exponents inside (-128, 128) (a NaN exponent means a NaN L: caught
+    // by the first test; v_max skips NaNs), |cos phi| <= 1 (false for NaN); the sin/cos argument x phi is
+    // then at most 10 pi for the powers the caller lets through
+    ordinary = (max(bits(qs) - 0x21800000u, bits(d) - 0x21800000u) < (0x5d800000u - 0x21800000u)) &&
+               (__builtin_fmaxf(abs_(e1), abs_(e2)) < 127.99999f) && (abs_(ca) <= 1.0f);
     return V4{pw * cs, pw * (n.x * sn), pw * (n.y * sn), pw * (n.z * sn)};
+}
+
+// `lanes`: the lanes whose result is used (the others may hold anything and do not force the general path).
+KIFS_DEV V4 quat_pow_shared(V4 q, float d, float qs, float x, float& dq_factor, bool lanes = true) {
+    bool ordinary = false;
+    V4 t{};
+    const bool power_ok = abs_(x) <= 1.0e5f;  // uniform: |x phi| <= pi |x| stays inside the sin/cos cores' range
+    if (__builtin_expect(power_ok, 1)) t = quat_pow_step<false>(q, d, qs, x, dq_factor, ordinary);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(lanes && !ordinary) != 0ull, 0))
+        t = quat_pow_step<true>(q, d, qs, x, dq_factor, ordinary);
+    return t;
 }
 
 KIFS_DEV V4 quat_pow(V4 q, float x) {
     const float d = quat_ijk2(q);
     const float qs = fmaf_(q.x, q.x, d);
-    return quat_pow_shared(q, d, qs, log2_wave(qs), x);
+    float unused;
+    return quat_pow_shared(q, d, qs, x, unused);
 }
 
 // ---- Julia ---------------------------------------------------------------------
@@ -199,11 +229,10 @@ KIFS_DEV float genjulia_sdf(const FrameParams& P, V3 p) {
     float qs = fmaf_(q.x, q.x, d);  // = quat_norm2(q)
     float dqs = 1.0f;
     const float pp = P.power * P.power;
-    const float pm1 = P.power - 1.0f;
     for (int i = 0; i < P.sdf_iters; ++i) {
-        const float L = log2_wave(qs);
-        dqs = dqs * (pp * exp2_wave(pm1 * L));  // pow(qs, power - 1)
-        V4 t = quat_pow_shared(q, d, qs, L, P.power);
+        float pw1;  // pow(qs, power - 1)
+        V4 t = quat_pow_shared(q, d, qs, P.power, pw1);
+        dqs = dqs * (pp * pw1);
         q = V4{t.x + P.c.x, t.y + P.c.y, t.z + P.c.z, t.w + P.c.w};
         d = quat_ijk2(q);
         qs = fmaf_(q.x, q.x, d);

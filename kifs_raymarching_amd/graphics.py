@@ -335,8 +335,15 @@ class GraphicState:
         `frames` (count, H, W, 4); stripe k of every shard goes to frame rows 8 * stripes[k]...
         Both are contiguous device tensors."""
         w, h = self.screen_data.width, self.screen_data.height
-        count = int(frames.shape[0]) if frames.dim() == 4 else 1
-        rows = int(shards.shape[-3])
+        if frames.dim() != 4 or shards.dim() != 4 or not (frames.is_contiguous() and shards.is_contiguous()):
+            raise ValueError("unpack_shard_async: frames (count, H, W, 4) and shards (count, rows, W, 4), contiguous")
+        count = int(frames.shape[0])
+        rows = int(shards.shape[1])
+        want_rows = sum(min(STRIPE_ROWS, h - s * STRIPE_ROWS) for s in stripes)
+        if (tuple(frames.shape[1:]) != (h, w, 4) or tuple(shards.shape) != (count, rows, w, 4) or rows != want_rows
+                or frames.element_size() != 1 or shards.element_size() != 1):
+            raise ValueError(f"unpack_shard_async: shapes {tuple(frames.shape)} / {tuple(shards.shape)} do not match "
+                             f"{count} frames of {h}x{w} and a shard of {want_rows} rows")
         if stream is not None and hasattr(stream, "cuda_stream"):
             stream = stream.cuda_stream
             if not stream:

@@ -131,3 +131,24 @@ def test_encoders_bit_exact(gs, oracle):
         got = gs.eval_math(fn, xs)
         want = np.array([enc(float(x), mode) for x in xs], dtype=F)
         assert (got == want).all(), mode
+
+
+def test_mid_range_reciprocal_and_sqrt_are_correctly_rounded_exhaustively(gs):
+    """rcp_mid / sqrt_mid (the generalised-Julia step's shortened 1/x and sqrt) against IEEE division and
+    square root for EVERY mantissa: a reciprocal's rounding depends on the mantissa only (scaling by a power
+    of two is exact in the normal range), a square root's on the mantissa and the exponent's parity; the
+    range's first and last binades are swept whole as well, and 0 for the square root (the acos tail)."""
+    mant = np.arange(1 << 23, dtype=np.uint32)
+    for fn, exps in ((9, (127, 127 - 60, 127 + 59)), (10, (127, 128, 127 - 60, 127 + 59))):
+        for e in exps:
+            xs = (mant | np.uint32(e << 23)).view(F)
+            got = gs.eval_math(fn, xs)
+            with np.errstate(all="ignore"):
+                want = (F(1.0) / xs) if fn == 9 else np.sqrt(xs)
+            bad = got.view(np.uint32) != want.astype(F).view(np.uint32)
+            assert not bad.any(), (fn, e, int(bad.sum()), xs[bad][:4], got[bad][:4], want[bad][:4])
+    assert gs.eval_math(10, np.array([0.0], dtype=F)).view(np.uint32)[0] == 0
+    rng = np.random.default_rng(11)
+    xs = np.exp2(rng.uniform(-60, 60, 2_000_000)).astype(F)
+    assert (gs.eval_math(9, xs).view(np.uint32) == (F(1.0) / xs).view(np.uint32)).all()
+    assert (gs.eval_math(10, xs).view(np.uint32) == np.sqrt(xs).view(np.uint32)).all()

@@ -150,6 +150,15 @@ def test_shard_argument_checks(gs, kifs):
                                                                  out.data_ptr(), sp, 8 * 256, st, len(st))
     assert un(arr(4, 2)) == 7 and un(arr(0), fp=100) == 3 and un(arr(0), sp=254) == 3
     gs.synchronize()
+    # the Python wrapper checks shapes before any pointer reaches the library
+    frames = torch.zeros((2, 40, 64, 4), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(ValueError):
+        gs.unpack_shard_async(frames, torch.zeros((2, 16, 64, 4), dtype=torch.uint8, device="cuda:0"), [0, 2, 4])  # 24 rows
+    with pytest.raises(ValueError):
+        gs.unpack_shard_async(frames[0], torch.zeros((2, 24, 64, 4), dtype=torch.uint8, device="cuda:0"), [0, 2, 4])
+    gs.unpack_shard_async(frames, torch.ones((2, 24, 64, 4), dtype=torch.uint8, device="cuda:0"), [0, 2, 4])
+    gs.synchronize()
+    assert int(frames.sum()) == 2 * 24 * 64 * 4
 
 
 def test_shardframes_on_gpu_world1(gs, kifs, oracle):
