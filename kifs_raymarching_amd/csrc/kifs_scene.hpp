@@ -358,6 +358,10 @@ KIFS_DEV float sierpinski_sdf(const FrameParams& P, V3 p, unsigned long long lan
     float scale = 1.0f;
     float n2 = dot(p, p);
     sierpinski_folds(P, p, n2, scale, lanes);
+    // scale is 2^k exactly (k folds made), so dividing by it is multiplying by 2^-k, itself exact: the
+    // same single rounding (if any: only in the denormal range).  2^-k by an exponent flip while it is a
+    // normal number (k <= 126: decided per launch); the division otherwise.
+    if (__builtin_expect(P.fold_iters <= 126, 1)) return (sqrt_(n2) - 2.0f) * from_bits(0x7f000000u - bits(scale));
     return (sqrt_(n2) - 2.0f) / scale;
 }
 
