@@ -1,15 +1,18 @@
 // kifs_kernels.hip -- gfx950 kernels of the raymarching library and their launchers.
 //
-// Three render kernels, all 256-thread workgroups over 32 x 8 pixel tiles taken from a tile ORDER
-// table, all fed by the kernel argument (BatchParams: frame constants + up to 32 views; scalar loads ->
-// SGPRs), all storing encoded pixels through an LDS tile so that every wave-level store instruction
-// writes two full 128-byte row segments:
-//   render_kernel<GROUP, PRIM>          the latency path: each wave owns an 8 x 8 block of its tile and
-//                                       marches its 64 rays from start to finish (lone frames, heatmap
-//                                       frames, diagnostics, small launches)
-//   render_group_kernel<GROUP, PRIM, T> the throughput path: the rays of T tiles share an LDS queue and
-//                                       are re-packed into full waves every few march steps
+// Four render kernels over 32 x 8 pixel tiles taken from a tile ORDER table, all fed by the kernel
+// argument (BatchParams: frame constants + up to 64 views; scalar loads -> SGPRs), all storing encoded
+// pixels through an LDS tile so that every wave-level store instruction writes two full 128-byte row
+// segments:
+//   render_kernel<GROUP, PRIM>          the latency path, 256 threads: each wave owns an 8 x 8 block of
+//                                       its tile and marches its 64 rays from start to finish (lone
+//                                       frames, heatmap frames, diagnostics, small launches)
+//   render_group_kernel<GROUP, PRIM, T> mid-size launches, 256 threads: the rays of T tiles share an LDS
+//                                       queue and are re-packed into full waves every few march steps
+//   render_wave_kernel<GROUP, PRIM>     big launches, 64 threads: one wave per tile with a private queue,
+//                                       no barrier, the orbit in its scalar form (VALU bound)
 //   render_bunny_quad_kernel            the bunny primitive, four lanes per pixel
+// (which one a launch gets: enqueue_batch in kifs_api.cpp, from the projected-disc tile count)
 // Tile order: a frame's run time is set by its longest rays (a lone wave pays ~5 cycles per
 // instruction whatever else the chip does), so workgroups start with the expensive tiles --
 // nearest-to-the-image-centre first on a geometry's first launches (the camera always looks at
