@@ -241,3 +241,35 @@ def test_wave_kernel_with_every_pixel_live_and_hitting(prim, gs, kifs, oracle):
         want = oracle_frame(oracle, kifs, screen, cams[k], gui, (100, 10, 6))
         assert (want != want[0, 0]).any(-1).mean() > 0.05, "the solid should be in view"
         assert (got[k] == want).all(), (prim, k, int((got[k] != want).any(-1).sum()))
+
+
+def test_shards_of_a_big_batch_take_the_wave_kernel(gs, kifs, oracle):
+    """Two ranks' shards of 64 orbit frames of the 1080p headline: each shard launch is heavy enough for
+    render_wave_kernel (one wave per tile), here with stripe rows, packed and in place.  Gathered == the
+    same 64 frames rendered whole; two of them against the oracle."""
+    import torch
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    W, H = w.screen.width, w.screen.height
+    gs.update_screen_data(w.screen)
+    gs.update_options(w.gui)
+    gs.set_iters(*w.iters)
+    cams = [orbit_camera(w, k) for k in range(64)]
+    stream = torch.cuda.Stream()
+    whole = torch.zeros((64, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    gs.render_batch_async([whole[i] for i in range(64)], cams, stream=stream)
+    assert gs.debug_last_group_tiles() == 0
+    gathered = torch.zeros_like(whole)
+    for r, weights in ((0, None), (1, None)):
+        stripes, rows = kifs.shard_stripes(H, r, 2, weights)
+        if r == 0:
+            gs.render_shard_async([gathered[i] for i in range(64)], cams, stripes, in_place=True, stream=stream)
+        else:
+            shard = torch.zeros((64, rows, W, 4), dtype=torch.uint8, device="cuda:0")
+            gs.render_shard_async([shard[i] for i in range(64)], cams, stripes, stream=stream)
+            gs.unpack_shard_async(gathered, shard, stripes, stream=stream)
+        assert gs.debug_last_group_tiles() == 0 and gs.debug_last_round_steps() > 0, r
+    stream.synchronize()
+    assert torch.equal(gathered, whole)
+    for k in (5, 63):
+        assert (gathered[k].cpu().numpy() == oracle_frame(oracle, kifs, w.screen, cams[k], w.gui, w.iters)).all(), k
