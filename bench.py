@@ -217,9 +217,9 @@ def pmc_traffic(workload_key, frames_per_launch=1):
         workload_key = f"{workload_key}@{frames_per_launch}"
     try:
         rec = json.loads(p.read_text()).get(workload_key)
-        return (rec["hbm_bytes_per_launch"] if rec else None), "profiles/pmc_traffic.json"
+        return (rec["hbm_bytes_per_launch"] if rec else None), "profiles/pmc_traffic.json", rec
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, None, None
 
 
 def main():
@@ -507,7 +507,7 @@ def main():
         launch_s = (m["kernel_ms"] if m["launches_timed"] else elapsed / args.steps * 1e3) / 1e3
         alg_bytes = 4.0 * W * rows0 * frames_per_launch  # rank 0's rows of the launch's frames
         achieved = alg_bytes / launch_s / 1e9
-        traffic, traffic_source = pmc_traffic(key, frames_per_launch) if world == 1 else (None, None)
+        traffic, traffic_source, pmc = pmc_traffic(key, frames_per_launch) if world == 1 else (None, None, None)
         if world == 1:
             parallelism = (f"1 GPU, {B} frame(s) of the sequence per launch"
                            + (f", {F} launches in flight" if F > 1 else ""))
@@ -558,6 +558,17 @@ def main():
             out["config"]["rows_per_rank"] = pipe.rows
             if calibration:
                 out["config"]["root_weight_calibration"] = calibration
+        if pmc and pmc.get("valu_instructions_per_launch") and pmc.get("kernel_cycles"):
+            # what actually bounds the kernel: the vector pipes.  From the same committed PMC passes: VALU
+            # wave-instructions per launch x 2.25 pipe cycles each (tools/microbench/valu_rate: a full chip
+            # sustains one plain wave64 VALU instruction per 2.25 cycles per SIMD; compares, packed and
+            # transcendental ones take 4 .. 8, so this is a lower bound of the pipes' busy time)
+            busy = pmc["valu_instructions_per_launch"] * 2.25 / (1024.0 * pmc["kernel_cycles"])
+            out["roofline"]["valu_issue"] = {"bound": "valu-issue", "frac_at_plain_rate": round(busy, 4),
+                                             "valu_instructions_per_launch": pmc["valu_instructions_per_launch"],
+                                             "kernel_cycles": pmc["kernel_cycles"], "simds": 1024,
+                                             "cycles_per_plain_instruction": 2.25,
+                                             "source": "profiles/pmc_traffic.json (rocprofv3 --pmc), tools/microbench/valu_rate.hip"}
         if secondary:
             out["secondary"] = secondary
         if check is not None:

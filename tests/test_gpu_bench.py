@@ -42,6 +42,8 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r["algorithmic_bytes_per_launch"] == 48 * 1920 * 1080 * 4
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
     assert r["traffic_source"] == "profiles/pmc_traffic.json"
+    v = r["valu_issue"]  # the bound that binds, from the committed PMC passes
+    assert v["bound"] == "valu-issue" and 0.5 < v["frac_at_plain_rate"] < 1.0 and v["simds"] == 1024
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mpixels/s" and c["cores"] >= 1 and c["value"] > 0
     sec = d["secondary"]

@@ -81,6 +81,9 @@ def main():
             traffic[key] = {"write_size_kib": round(rec["WRITE_SIZE"], 2), "fetch_size_kib": round(rec["FETCH_SIZE"], 2),
                             "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "kernel": rec["kernel"],
                             "camera": "orbit", "round": rnd}
+            if rec.get("SQ_INSTS_VALU") and rec.get("GRBM_GUI_ACTIVE"):
+                traffic[key]["valu_instructions_per_launch"] = int(rec["SQ_INSTS_VALU"])
+                traffic[key]["kernel_cycles"] = int(rec["GRBM_GUI_ACTIVE"] / 8.0)
         if rec.get("GRBM_GUI_ACTIVE"):
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the launch's duration in shader cycles
             cycles = rec["GRBM_GUI_ACTIVE"] / 8.0
