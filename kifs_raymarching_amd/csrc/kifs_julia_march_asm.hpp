@@ -1,6 +1,6 @@
 // The asm statement of julia_fast_march (kifs_scene.hpp), included once per variant with
-// KIFS_JULIA_DIVSQRT / KIFS_JULIA_DIVSQRT_OUT_OF_LINE, KIFS_FAST_TRIP / KIFS_JULIA_PROLOGUE / KIFS_JULIA_C_OPERANDS
-// defined by the includer.  See the
+// KIFS_JULIA_DIVSQRT / KIFS_JULIA_DIVSQRT_OUT_OF_LINE, KIFS_FAST_TRIP / KIFS_TRIP_EXIT / KIFS_JULIA_PROLOGUE /
+// KIFS_JULIA_C_OPERANDS defined by the includer.  See the
 // register map and the description there.
     asm volatile(
         "s_setprio 3\n"   // after the culls only rays that reach the fractal get here: issue them first
@@ -34,9 +34,9 @@
         "s_cmp_eq_u32 s96, 0\n"
         "s_cbranch_scc1 14f\n"
         "13:\n"
-        KIFS_FAST_TRIP KIFS_FAST_TRIP KIFS_FAST_TRIP
+        KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP
         "s_cbranch_execz 14f\n"
-        KIFS_FAST_TRIP KIFS_FAST_TRIP KIFS_FAST_TRIP
+        KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP
         "s_cbranch_execz 14f\n"
         "s_sub_u32 s96, s96, 1\n"
         "s_cmp_lg_u32 s96, 0\n"

@@ -660,6 +660,7 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
     unsigned long long hit_mask = 0, live_out;
     if constexpr (THROUGHPUT) {
 #define KIFS_FAST_TRIP KIFS_FAST_TRIP_SCALAR
+#define KIFS_TRIP_EXIT "s_cbranch_execz 14f\n"  /* scalar slots are free where the vector pipe is the limit: test every trip */
 #define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_SCALAR
 #define KIFS_JULIA_C_OPERANDS [cy] "s"(P.c.y), [cz] "s"(P.c.z), [cw] "s"(P.c.w), [cx] "s"(P.c.x)
         if constexpr (SHORT_DIVSQRT) {
@@ -676,11 +677,13 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 #undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
         }
 #undef KIFS_FAST_TRIP
+#undef KIFS_TRIP_EXIT
 #undef KIFS_JULIA_PROLOGUE
 #undef KIFS_JULIA_C_OPERANDS
     } else {
         const F2 cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x};
 #define KIFS_FAST_TRIP KIFS_FAST_TRIP_PACKED
+#define KIFS_TRIP_EXIT  /* a lone wave pays for every instruction: test every third trip only */
 #define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_PACKED
 #define KIFS_JULIA_C_OPERANDS [cyz] "s"(cyz), [cw0] "s"(cw0), [c0x] "s"(c0x)
         if constexpr (SHORT_DIVSQRT) {
@@ -697,6 +700,7 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 #undef KIFS_JULIA_DIVSQRT_OUT_OF_LINE
         }
 #undef KIFS_FAST_TRIP
+#undef KIFS_TRIP_EXIT
 #undef KIFS_JULIA_PROLOGUE
 #undef KIFS_JULIA_C_OPERANDS
     }
