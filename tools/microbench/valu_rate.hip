@@ -40,6 +40,15 @@ __global__ void k(float* sink, unsigned long long* clk, float seed) {
                          "v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
                          "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        } else if (MODE == 5 || MODE == 6) {  // 16 v_fma_f32 with only the low 32 (5) or low 8 (6) lanes enabled
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, %10\n"
+                         "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                         "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                         "s_mov_b64 exec, s[20:21]\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(b), "v"(c), "s"(MODE == 5 ? 0xffffffffull : 0xffull) : "s20", "s21");
         } else if (MODE == 4) {  // 16 v_cmp + v_cndmask pairs (8 pairs)
             asm volatile("v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %2, vcc\n v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %1, %1, %2, vcc\n"
                          "v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %2, vcc\n v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %1, %1, %2, vcc\n"
@@ -78,5 +87,6 @@ void run(const char* name) {
 
 int main() {
     run<0>("v_fma_f32"); run<1>("v_pk_fma_f32"); run<2>("v_pk_mul_f32"); run<3>("v_mul_f32"); run<4>("v_cmp+cndmask");
+    run<5>("v_fma lanes<32"); run<6>("v_fma lanes<8");
     return 0;
 }
