@@ -226,6 +226,14 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
         // the wave-level quick exit uses a sphere 9 % larger again; like the culls, not in heatmap mode
         P->quick_cull_n2 = (sane && !o.is_heatmap && o.max_iterations > 0) ? 1.2f * R * R : 0.0f;
         P->inv_height = 1.0f / c->screen.height;
+        // Tile-level form (render_wave_kernel): for an orthonormal camera matrix |d| >= 1 and two pixel
+        // centres of a 32 x 8 tile are at most (31, 7) pixels = (31, 7) * 2 / height apart in uv, so a
+        // ray of the tile and the ray through the tile's centre differ by at most
+        // asin(|(31, 7)| / height) <= 1.05 * 31.8 / height radians (the ratio is below 0.5 from 64 rows);
+        // 34 / height leaves 2 % for the matrix check's tolerance.  enqueue_batch() switches it off when
+        // a view's matrix is not orthonormal.
+        P->tile_cull_sqrtk = std::sqrt(P->quick_cull_n2);
+        P->tile_cull_beta = (P->quick_cull_n2 > 0.0f && c->screen.height >= 64.0f) ? 34.0f / c->screen.height : 0.0f;
     }
     {   // Ray re-queuing (render_group_kernel): rounds of this many march steps -- 16 for the Julia
         // pipeline, 8 for the others (measured; KIFS_ROUND_STEPS overrides, 0 switches it off).
@@ -439,6 +447,14 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         v.m1 = {cam.matrix[1][0], cam.matrix[1][1], cam.matrix[1][2]};
         v.m2 = {cam.matrix[2][0], cam.matrix[2][1], cam.matrix[2][2]};
         v.out = reinterpret_cast<uint32_t*>(outs[i]);
+        if (P.tile_cull_beta > 0.0f) {  // the tile-level cull's angle bound assumes an orthonormal matrix
+            const kifs::V3* m[3] = {&v.m0, &v.m1, &v.m2};
+            for (int a = 0; a < 3; ++a)
+                for (int b = a; b < 3; ++b) {
+                    const double dot = double(m[a]->x) * m[b]->x + double(m[a]->y) * m[b]->y + double(m[a]->z) * m[b]->z;
+                    if (!(std::fabs(dot - (a == b ? 1.0 : 0.0)) <= 1.0e-3)) P.tile_cull_beta = 0.0f;
+                }
+        }
     }
     P.origin = B.view[0].origin;
     P.m0 = B.view[0].m0;

@@ -62,6 +62,11 @@ struct FrameParams {
     // form of the bounding-sphere cull, evaluated before any ray is set up.  0 disables it.
     float quick_cull_n2;                // 1.2 (B + epsilon)^2: well outside cull_n2
     float inv_height;                   // ~1 / height (the quick test needs no exact uv)
+    // Tile-level form of the same exit (tile_is_culled in kifs_kernels.hip): the quick test at the tile's
+    // centre against a sphere grown by what the tile subtends.  tile_cull_beta bounds the angle (radians)
+    // between the centre's ray and any ray of a 32 x 8 tile; 0 disables the test (camera matrix not
+    // orthonormal, frame under 64 rows, quick cull off).  tile_cull_sqrtk = sqrt(quick_cull_n2).
+    float tile_cull_beta, tile_cull_sqrtk;
     uint32_t background_rgba;           // the encoded background pixel (same encoder, run on the host)
     // Ray re-queuing (render_kernel): march steps per round between two re-packings of the
     // workgroup's surviving rays into full waves; 0 = every wave marches its own 64 pixels to the end.

@@ -273,3 +273,80 @@ def test_shards_of_a_big_batch_take_the_wave_kernel(gs, kifs, oracle):
     assert torch.equal(gathered, whole)
     for k in (5, 63):
         assert (gathered[k].cpu().numpy() == oracle_frame(oracle, kifs, w.screen, cams[k], w.gui, w.iters)).all(), k
+
+
+def test_tile_level_exit_with_odd_cameras(gs, kifs, oracle):
+    """render_wave_kernel leaves whole tiles after ONE test at the tile's centre (tile_is_culled), whose
+    angle bound assumes an orthonormal camera matrix and a camera outside the grown sphere.  One launch of
+    48 views whose cameras stress that: just outside and just inside the bounding sphere, very far, matrices
+    that are scaled, sheared or mirrored (raw CameraUniform images: the boundary takes any 64 bytes), a camera
+    that looks away from the fractal, and one that looks past it.  Every frame == the oracle on the same bytes."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from kifs_raymarching_amd._lib import CameraUniform
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    screen = kifs.ScreenData(1600, 900)  # x 48 views: past the load at which Julia launches go one wave per tile
+    gs.update_screen_data(screen)
+    gs.update_options(w.gui)
+    gs.set_iters(*w.iters)
+
+    def raw(cam, edit=None):
+        u = cam.into_buffer_data()
+        if edit:
+            edit(u)
+        return u
+
+    def scale_row(r, f):
+        def e(u):
+            for k in range(3):
+                u.matrix[r][k] *= f
+        return e
+
+    def shear(u):
+        for k in range(3):
+            u.matrix[1][k] += 0.4 * u.matrix[2][k]
+
+    def look_away(u):
+        for k in range(3):
+            u.matrix[0][k] = -u.matrix[0][k]
+
+    def look_past(u):  # the forward axis tilted by about 40 degrees: the fractal sits at the frame's edge
+        for k in range(3):
+            u.matrix[0][k] = 0.77 * u.matrix[0][k] + 0.64 * u.matrix[1][k]
+
+    CD = kifs.CameraData
+    special = [raw(CD(origin_distance=2.0 + 1e-3, min_distance=1.0)), raw(CD(origin_distance=2.2, min_distance=1.0, phi=1.0)),
+               raw(CD(origin_distance=2.32, min_distance=1.0, theta=0.4)), raw(CD(origin_distance=2.45, phi=2.0)),
+               raw(CD(origin_distance=40.0)), raw(CD(origin_distance=5.0), scale_row(1, 1.5)),
+               raw(CD(origin_distance=5.0), scale_row(2, 0.5)), raw(CD(origin_distance=4.0), scale_row(0, 2.0)),
+               raw(CD(origin_distance=5.0, phi=0.7), shear), raw(CD(origin_distance=5.0, theta=-0.5), scale_row(1, -1.0)),
+               raw(CD(origin_distance=5.0), look_away), raw(CD(origin_distance=3.0, phi=0.3), look_past)]
+    cams = special + [raw(orbit_camera(w, k)) for k in range(48 - len(special))]
+    outs = torch.zeros((48, 900, 1600, 4), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    gs.render_batch_async([outs[i] for i in range(48)], cams, stream=stream)
+    stream.synchronize()
+    assert gs.debug_last_group_tiles() == 0 and gs.debug_last_round_steps() > 0
+    got = outs.cpu().numpy()
+    s = oracle.from_bytes(oracle.Screen, kifs.uniform_bytes(screen.into_buffer_data()))
+    o = oracle.from_bytes(oracle.Options, kifs.uniform_bytes(w.gui.into_buffer_data()))
+    seen_fractal = 0
+    for k in list(range(len(special))) + [20, 47]:
+        c = oracle.from_bytes(oracle.Camera, kifs.uniform_bytes(cams[k]))
+        want = oracle.render(s, c, o, oracle.iters(*w.iters), encode=1)
+        seen_fractal += int((want != want[0, 0]).any())
+        assert (got[k] == want).all(), (k, int((got[k] != want).any(-1).sum()))
+    assert seen_fractal >= 10
+    # orthonormal views alone take the tile-level exit; the launch above had it switched off by the odd ones
+    cams2 = [raw(orbit_camera(w, k)) for k in range(44)] + special[:4]
+    outs.zero_()
+    gs.render_batch_async([outs[i] for i in range(48)], cams2, stream=stream)
+    stream.synchronize()
+    assert gs.debug_last_group_tiles() == 0
+    got = outs.cpu().numpy()
+    for k in (0, 30, 44, 45, 46, 47):
+        c = oracle.from_bytes(oracle.Camera, kifs.uniform_bytes(cams2[k]))
+        want = oracle.render(s, c, o, oracle.iters(*w.iters), encode=1)
+        assert (got[k] == want).all(), (k, int((got[k] != want).any(-1).sum()))

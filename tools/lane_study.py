@@ -49,9 +49,14 @@ def main():
     pos = [np.full(n, o[k], dtype=F) for k in range(3)]
     tile = (ys.ravel() // 8) * ((W + 31) // 32) + xs.ravel() // 32
     tot = dict(useful=0.0, tile=0.0, split=0.0, frame=0.0, packed=0.0, packed2=0.0, steps=0, raysteps=0,
-               r_tile=0.0, r_pool=0.0, r_pool_split=0.0)
+               r_tile=0.0, r_pool=0.0, r_pool_split=0.0, r_g2=0.0, r_g4=0.0, r_g16=0.0, r_tile_split=0.0, r_tile_sorted=0.0, r_tile_full=0.0)
     R = 16
-    wave_of = {k: np.full(n, -1, dtype=np.int64) for k in ("r_tile", "r_pool", "r_pool_split")}
+    ROUND_KEYS = ("r_tile", "r_tile_split", "r_tile_full", "r_tile_sorted", "r_g2", "r_g4", "r_g16", "r_pool", "r_pool_split")
+    wave_of = {k: np.full(n, -1, dtype=np.int64) for k in ROUND_KEYS}
+    tiles_x = (W + 31) // 32
+    g2 = (ys.ravel() // 16) * tiles_x + xs.ravel() // 32                 # 2 tiles: 32 x 16
+    g4 = (ys.ravel() // 16) * ((W + 63) // 64) + xs.ravel() // 64       # 4 tiles: 64 x 16
+    g16 = (ys.ravel() // 32) * ((W + 127) // 128) + xs.ravel() // 128   # 16 tiles: 128 x 32
     step = 0
     while live.any() and step < s.max_iterations:
         idx = np.nonzero(live)[0]
@@ -125,9 +130,15 @@ def main():
                 return out
             zero = np.zeros(idx.size, dtype=np.int64)
             wave_of["r_tile"][idx] = assign([zero, tl])                               # per tile (render_wave_kernel)
+            wave_of["r_tile_split"][idx] = assign([outside.astype(np.int64), tl])     # a tile's rays, outside ones first
+            wave_of["r_tile_full"][idx] = assign([(trips < s.sdf_iters).astype(np.int64) + outside, tl])  # never-escaping / escaping / outside
+            wave_of["r_tile_sorted"][idx] = assign([-trips, tl])                      # a tile's rays by orbit length at the round's first step
+            wave_of["r_g2"][idx] = assign([zero, g2[idx]])                            # pools of 2 / 4 / 16 adjacent tiles
+            wave_of["r_g4"][idx] = assign([zero, g4[idx]])
+            wave_of["r_g16"][idx] = assign([zero, g16[idx]])
             wave_of["r_pool"][idx] = assign([tl, zero])                               # one pool, tile order
             wave_of["r_pool_split"][idx] = assign([tl, outside.astype(np.int64)])     # inside / outside pools
-        for k in ("r_tile", "r_pool", "r_pool_split"):
+        for k in ROUND_KEYS:
             _, inv = np.unique(wave_of[k][idx], return_inverse=True)
             mt = np.zeros(inv.max() + 1)
             np.maximum.at(mt, inv, trips)
@@ -154,7 +165,10 @@ def main():
     for k, label in (("tile", "waves of one tile's rays"), ("split", "… outside rays apart, sorted by orbit length"),
                      ("packed", "full waves of the frame's rays in tile order"), ("packed2", "… outside rays apart"),
                      ("frame", "waves of any 64 rays of the frame, sorted"),
-                     ("r_tile", "ROUNDS of 16: waves of one tile's rays"), ("r_pool", "ROUNDS of 16: one pool of all rays, tile order"),
+                     ("r_tile", "ROUNDS of 16: waves of one tile's rays"), ("r_tile_split", "ROUNDS of 16: one tile, outside rays first"),
+                     ("r_tile_full", "ROUNDS of 16: one tile, full-orbit / escaping / outside"), ("r_tile_sorted", "ROUNDS of 16: one tile, sorted by orbit length"),
+                     ("r_g2", "ROUNDS of 16: pools of 2 tiles (32x16)"),
+                     ("r_g4", "ROUNDS of 16: pools of 4 tiles (64x16)"), ("r_g16", "ROUNDS of 16: pools of 16 tiles (128x32)"), ("r_pool", "ROUNDS of 16: one pool of all rays, tile order"),
                      ("r_pool_split", "ROUNDS of 16: inside / outside pools")):
         print(f"  {label:48s}: vector work {tot[k] / u:.2f} x the lanes' own ({100 * u / tot[k]:.0f} % useful)")
 
