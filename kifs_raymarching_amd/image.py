@@ -15,18 +15,22 @@ def _chunk(tag: bytes, data: bytes) -> bytes:
     return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
 
 
-def write_png(path, rgba: np.ndarray, keep_alpha: bool = False):
-    """`rgba`: (H, W, 4) uint8, rows top to bottom (y = 0 is the top row, entry.wgsl:54)."""
+def png_bytes(rgba: np.ndarray, keep_alpha: bool = False, level: int = 6) -> bytes:
+    """`rgba`: (H, W, 4) uint8, rows top to bottom (y = 0 is the top row, entry.wgsl:54) -> a PNG file image."""
     a = np.ascontiguousarray(rgba, dtype=np.uint8)
     if a.ndim != 3 or a.shape[2] != 4:
-        raise ValueError("write_png: expected an (H, W, 4) uint8 array")
+        raise ValueError("png_bytes: expected an (H, W, 4) uint8 array")
     h, w, _ = a.shape
     body = a if keep_alpha else a[..., :3]
     raw = np.concatenate([np.zeros((h, 1), dtype=np.uint8), body.reshape(h, -1)], axis=1).tobytes()
     ihdr = struct.pack(">IIBBBBB", w, h, 8, 6 if keep_alpha else 2, 0, 0, 0)
+    return (b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(raw, level))
+            + _chunk(b"IEND", b""))
+
+
+def write_png(path, rgba: np.ndarray, keep_alpha: bool = False):
     with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(raw, 6))
-                + _chunk(b"IEND", b""))
+        f.write(png_bytes(rgba, keep_alpha))
 
 
 def write_ppm(path, rgba: np.ndarray):
@@ -38,8 +42,9 @@ def write_ppm(path, rgba: np.ndarray):
 
 
 def read_png_rgb(path) -> np.ndarray:
-    """Minimal reader for files written by write_png (filter type 0 rows only)."""
-    data = open(path, "rb").read()
+    """Minimal reader for files written by write_png (filter type 0 rows only); `path` may also be the
+    file's bytes."""
+    data = path if isinstance(path, (bytes, bytearray)) else open(path, "rb").read()
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
     pos, idat, w = 8, b"", 0
     h = channels = 0
