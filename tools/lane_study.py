@@ -51,6 +51,24 @@ def main():
     tot = dict(useful=0.0, tile=0.0, split=0.0, frame=0.0, packed=0.0, packed2=0.0, steps=0, raysteps=0,
                r_tile=0.0, r_pool=0.0, r_pool_split=0.0, r_g2=0.0, r_g4=0.0, r_g16=0.0, r_tile_split=0.0, r_tile_sorted=0.0, r_tile_full=0.0)
     R = 16
+    # round-length schedules for one tile per wave (render_wave_kernel): name -> boundaries; each chunk-round
+    # also pays ROUND_OVERHEAD cycles (queue traffic, direction rebuilt, ballots: ~110 instructions)
+    ROUND_OVERHEAD = 250.0
+    def boundaries(lengths):
+        b, s = set(), 0
+        for L in lengths:
+            b.add(s)
+            s += L
+        while s < 4096:
+            b.add(s)
+            s += lengths[-1]
+        return b
+    SCHEDULES = {"8": boundaries([8]), "12": boundaries([12]), "16": boundaries([16]), "24": boundaries([24]), "32": boundaries([32]),
+                 "4,4,8,16..": boundaries([4, 4, 8, 16]), "8,8,16..": boundaries([8, 8, 16]), "8,16,32..": boundaries([8, 16, 32]),
+                 "8,8,16,32..": boundaries([8, 8, 16, 32]), "4,8,16,32..": boundaries([4, 8, 16, 32]), "16,16,32..": boundaries([16, 16, 32]),
+                 "8,24,32..": boundaries([8, 24, 32]), "8,8,16,32,64..": boundaries([8, 8, 16, 32, 64])}
+    sched_wave = {k: np.full(n, -1, dtype=np.int64) for k in SCHEDULES}
+    sched_cost = {k: 0.0 for k in SCHEDULES}
     ROUND_KEYS = ("r_tile", "r_tile_split", "r_tile_full", "r_tile_sorted", "r_g2", "r_g4", "r_g16", "r_pool", "r_pool_split")
     wave_of = {k: np.full(n, -1, dtype=np.int64) for k in ROUND_KEYS}
     tiles_x = (W + 31) // 32
@@ -138,6 +156,27 @@ def main():
             wave_of["r_g16"][idx] = assign([zero, g16[idx]])
             wave_of["r_pool"][idx] = assign([tl, zero])                               # one pool, tile order
             wave_of["r_pool_split"][idx] = assign([tl, outside.astype(np.int64)])     # inside / outside pools
+        for k, bset in SCHEDULES.items():
+            if step in bset:
+                order = np.lexsort([np.zeros(idx.size, dtype=np.int64), tile[idx]])
+                last = tile[idx][order]
+                grp = np.cumsum(np.r_[True, last[1:] != last[:-1]]) - 1
+                first = np.r_[0, np.nonzero(np.diff(grp))[0] + 1]
+                start = np.zeros(grp.size, dtype=np.int64)
+                start[first] = first
+                start = np.maximum.accumulate(start)
+                wid = np.empty(idx.size, dtype=np.int64)
+                wid[order] = grp * 1000000 + (np.arange(grp.size) - start) // 64
+                sched_wave[k][idx] = wid
+                sched_cost[k] += 64.0 * ROUND_OVERHEAD * np.unique(wid).size
+            _, inv = np.unique(sched_wave[k][idx], return_inverse=True)
+            mt = np.zeros(inv.max() + 1)
+            np.maximum.at(mt, inv, trips)
+            anyin = np.zeros(inv.max() + 1, dtype=bool)
+            np.logical_or.at(anyin, inv, ~outside)
+            anyout = np.zeros(inv.max() + 1, dtype=bool)
+            np.logical_or.at(anyout, inv, outside)
+            sched_cost[k] += float((64.0 * (np.where(anyin, TRIP * mt + TAIL, 0.0) + np.where(anyout, OUT, 0.0))).sum())
         for k in ROUND_KEYS:
             _, inv = np.unique(wave_of[k][idx], return_inverse=True)
             mt = np.zeros(inv.max() + 1)
@@ -171,6 +210,9 @@ def main():
                      ("r_g4", "ROUNDS of 16: pools of 4 tiles (64x16)"), ("r_g16", "ROUNDS of 16: pools of 16 tiles (128x32)"), ("r_pool", "ROUNDS of 16: one pool of all rays, tile order"),
                      ("r_pool_split", "ROUNDS of 16: inside / outside pools")):
         print(f"  {label:48s}: vector work {tot[k] / u:.2f} x the lanes' own ({100 * u / tot[k]:.0f} % useful)")
+    print("  round-length schedules, one tile per wave, with the rounds' own overhead:")
+    for k, c in sched_cost.items():
+        print(f"    rounds of {k:16s}: {c / u:.3f} x")
 
 
 if __name__ == "__main__":
