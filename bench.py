@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--shard", default="stripes", choices=["stripes", "bands", "frames"],
                     help="N > 1: interleaved 8-row stripes of every frame gathered to rank 0 (default), "
                          "contiguous row bands gathered to rank 0, or whole frames per rank")
+    ap.add_argument("--gather", default="sparse", choices=["sparse", "dense"],
+                    help="N > 1, row shards: peers send only the 32 x 8 tiles that hold something and rank 0 fills in "
+                         "the background (default), or every row as it is")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1, row shards: frames per step = N x frames-per-launch (weak) or frames-per-launch")
     ap.add_argument("--root-weight", default="auto",
@@ -233,7 +236,7 @@ def main():
     import torch.distributed as dist
 
     import kifs_raymarching_amd as K
-    from kifs_raymarching_amd.bands import FrameStream, ShardFrames
+    from kifs_raymarching_amd.bands import FrameStream, ShardFrames, SparseShardFrames
     from kifs_raymarching_amd.configs import HEADLINE, WORKLOADS, orbit_camera
 
     rank = int(os.environ.get("RANK", "0"))
@@ -339,10 +342,34 @@ def main():
         weights = None
         if not contiguous and root_weight != 1:
             weights = [root_weight] + [1] * (world - 1)
-        sf = ShardFrames(W, H, rank, world, device, frames_per_step=frames_per_step, buffers=2,
-                         weights=weights, contiguous=contiguous,
-                         unpack=lambda frames, shards, stripes: gs.unpack_shard_async(
-                             frames, shards, stripes, stream=streams[0]))
+        if args.gather == "sparse":
+            slots = {}  # per payload buffer: the record count on the device, in pinned host memory, and its event
+
+            def pack(shards, stripes, records):
+                key_ = records.data_ptr()
+                if key_ not in slots:
+                    slots[key_] = (torch.zeros(1, dtype=torch.int32, device=device),
+                                   torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                n_dev, n_host, ev = slots[key_]
+                gs.pack_sparse_async(shards, stripes, records, n_dev, n_host, stream=streams[0], encode=args.encode)
+                ev.record(streams[0])
+
+                def count():
+                    ev.synchronize()
+                    return int(n_host[0])
+                return count
+            sf = SparseShardFrames(
+                W, H, rank, world, device, frames_per_step=frames_per_step, buffers=2, weights=weights,
+                contiguous=contiguous, pack=pack, count_group=count_group, fill_stream=fill_stream,
+                unpack_sparse=lambda frames, records, n, stripes: gs.unpack_sparse_async(
+                    frames, records, n, stripes, stream=streams[0]),
+                fill=lambda frames, stripes: gs.fill_shard_async(
+                    frames, stripes, stream=torch.cuda.current_stream(), encode=args.encode))
+        else:
+            sf = ShardFrames(W, H, rank, world, device, frames_per_step=frames_per_step, buffers=2,
+                             weights=weights, contiguous=contiguous,
+                             unpack=lambda frames, shards, stripes: gs.unpack_shard_async(
+                                 frames, shards, stripes, stream=streams[0]))
 
         def render(outs, first_frame, stripes, in_place):
             cams = cameras(first_frame, len(outs), camera_mode)
@@ -396,6 +423,11 @@ def main():
 
     # ---- the headline sequence
     sharded = world > 1 and args.shard in ("stripes", "bands")
+    count_group = fill_stream = None
+    if sharded and args.gather == "sparse":
+        # message sizes travel between the hosts over a CPU group, beside the RCCL transfers
+        count_group = dist.new_group(backend="gloo") if args.backend == "nccl" else None
+        fill_stream = torch.cuda.Stream(device=device)
     root_weight, calibration = 1, None
     if sharded:
         frames_per_step = B * world if args.scaling == "weak" else B
@@ -517,7 +549,9 @@ def main():
                               "8-row stripes dealt round-robin"
                               + (f", rank 0 weighted x{root_weight}" if root_weight != 1 else ""))
                            + f") of {frames_per_step} frames per step, gathered into rank 0's frames by grouped "
-                           "RCCL point-to-point over xGMI + stripe unpack")
+                           "RCCL point-to-point over xGMI"
+                           + (": peers send the 32x8 tiles that hold something, rank 0 fills in the background"
+                              if args.gather == "sparse" else " + stripe unpack"))
         else:
             parallelism = (f"{world} GPUs x whole frames (frame-parallel, {B} per launch), one process per GPU, "
                            + ("finished frames sent to rank 0 by grouped RCCL p2p" if args.deliver == "root"
@@ -556,6 +590,9 @@ def main():
         if sharded:
             out["config"]["root_weight"] = root_weight
             out["config"]["rows_per_rank"] = pipe.rows
+            out["config"]["gather"] = args.gather
+            if args.gather == "sparse" and pipe.tiles_seen:
+                out["config"]["tiles_sent_fraction"] = round(pipe.records_sent / pipe.tiles_seen, 4)
             if calibration:
                 out["config"]["root_weight_calibration"] = calibration
         if pmc and pmc.get("valu_instructions_per_launch") and pmc.get("kernel_cycles"):

@@ -218,6 +218,41 @@ int kifs_unpack_shard_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t*
                             size_t shard_pitch, size_t shard_stride, const int* stripes,
                             int n_stripes);
 
+/* ---- sparse shards: a peer's rows without their background tiles -----------------------------
+ * The root of a gather takes each peer's rows over ONE xGMI link (~19 Gpixel/s inbound per link), a
+ * GPU renders several times faster, and nine tenths of a 1080p frame of these scenes are the
+ * background colour (the clear colour of the reference's render pass, render.rs:300-330).  So a peer
+ * sends only the 32 x 8 tiles of its packed shards that hold a pixel other than the background, and
+ * the root writes the background itself.  Lossless for any frame: a frame with no background at
+ * all costs 1.6 % more than its dense form.
+ *
+ * A RECORD is KIFS_SPARSE_RECORD_BYTES = 1040 bytes: uint32 tile id, three zero words, then the tile's
+ * 8 rows of 32 RGBA8 pixels (pixels outside the frame hold the background).
+ * Tile id = (shard i * n_stripes + stripe slot k) * tiles_x + tile column, tiles_x = ceil(W / 32).
+ *
+ * kifs_pack_sparse_async: appends one record per non-background tile of the `count` packed shards
+ *   (layout as kifs_unpack_shard_async's dev_shards; `stripes` the shard's list) to dev_records
+ *   (16-byte aligned, room for capacity_records >= count * n_stripes * tiles_x records), in no
+ *   particular order, and leaves their number in *dev_n_records (zeroed by the call, on the
+ *   stream); host_n_records, when not NULL (pinned host memory), receives an asynchronous copy of
+ *   it -- valid once the stream has reached that point.  `encode` selects the background pixel
+ *   (the context's options, encoded as the render would).
+ * kifs_unpack_sparse_async: the root's side.  Writes records [0, n_records) to their rows of the
+ *   frames dev_frames + i * frame_stride; records whose id is out of range are skipped.
+ * kifs_fill_shard_async: the background over the rows of the listed stripes of `count` frames
+ *   (what the records leave out; any order with kifs_unpack_sparse_async's stream, before it). */
+#define KIFS_SPARSE_RECORD_BYTES 1040
+int kifs_pack_sparse_async(kifs_ctx* ctx, void* hip_stream, int count, const uint8_t* dev_shards,
+                           size_t shard_pitch, size_t shard_stride, const int* stripes, int n_stripes,
+                           int encode, uint8_t* dev_records, size_t capacity_records,
+                           uint32_t* dev_n_records, uint32_t* host_n_records);
+int kifs_unpack_sparse_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t* dev_frames,
+                             size_t frame_pitch, size_t frame_stride, const uint8_t* dev_records,
+                             size_t n_records, const int* stripes, int n_stripes);
+int kifs_fill_shard_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t* dev_frames,
+                          size_t frame_pitch, size_t frame_stride, const int* stripes, int n_stripes,
+                          int encode);
+
 /* ---- single-process multi-GPU ------------------------------------------------------
  * For a host that drives all GPUs of a node from one process (the reference's host is one
  * process, application.rs:37-48).  A kifs_multi owns one context per listed device; a render deals

@@ -272,8 +272,6 @@ class ShardFrames:
         if rank == root:
             self._frames = [torch.zeros((self.count, height, width, 4), dtype=torch.uint8, device=self.device)
                             for _ in range(buffers)]
-            self._recv = [[torch.zeros(shape(r), dtype=torch.uint8, device=self.device) if r != root else None
-                           for r in range(world)] for _ in range(buffers)]
             self._mine = None
         else:
             self._frames = [None] * buffers
@@ -281,6 +279,15 @@ class ShardFrames:
         self._works: List[Optional[list]] = [None] * buffers
         self._staged = (world > 1 and self.device.type == "cuda"
                         and dist.get_backend(group) == "gloo")  # rehearsal on one GPU, see BandFrame
+        self._alloc_transfer_buffers()
+
+    def _alloc_transfer_buffers(self):
+        """What the root receives into (and, for a gloo rehearsal with device tensors, the host staging)."""
+        rank, root, world, buffers = self.rank, self.root, self.world, self.buffers
+        shape = lambda r: (self.count, self.rows[r], self.width, 4)
+        if rank == root:
+            self._recv = [[torch.zeros(shape(r), dtype=torch.uint8, device=self.device) if r != root else None
+                           for r in range(world)] for _ in range(buffers)]
         if self._staged:
             if rank == root:
                 self._host = [[torch.empty(shape(r), dtype=torch.uint8) if r != root else None
@@ -350,3 +357,218 @@ class ShardFrames:
             outs, in_place = self.targets(k)
             render_shard(outs, k * self.count, self.my_stripes, in_place)
         self.gather_async(k)
+
+
+# ---- sparse shards: only the tiles that hold something cross the links -------------------------------
+SPARSE_RECORD_BYTES = 1040  # KIFS_SPARSE_RECORD_BYTES: uint32 id, three zero words, 8 rows of 32 RGBA8 pixels
+_TILE_W = 32
+
+
+def _tiles_x(width: int) -> int:
+    return (width + _TILE_W - 1) // _TILE_W
+
+
+def pack_sparse_torch(shards: torch.Tensor, stripes, height: int, background_rgba: int) -> torch.Tensor:
+    """CPU form of kifs_pack_sparse_async (tests and the gloo path): (count, rows, W, 4) packed shards ->
+    (n, 1040) uint8 records of the tiles that hold a pixel other than `background_rgba` (little-endian
+    R | G << 8 | B << 16 | A << 24), in tile-id order."""
+    count, rows, width, _ = shards.shape
+    tx, ns = _tiles_x(width), len(stripes)
+    bg = torch.tensor([(background_rgba >> s) & 255 for s in (0, 8, 16, 24)], dtype=torch.uint8)
+    padded = bg.expand(count, ns * STRIPE_ROWS, tx * _TILE_W, 4).clone()
+    padded[:, :rows, :width] = shards.cpu()
+    tiles = padded.view(count, ns, STRIPE_ROWS, tx, _TILE_W, 4).permute(0, 1, 3, 2, 4, 5).reshape(-1, STRIPE_ROWS * _TILE_W * 4)
+    keep = (tiles.view(-1, STRIPE_ROWS * _TILE_W, 4) != bg).any(-1).any(-1).nonzero().flatten()
+    records = torch.zeros((keep.numel(), SPARSE_RECORD_BYTES), dtype=torch.uint8)
+    records[:, :4] = keep.to(torch.int32).view(-1, 1).contiguous().view(torch.uint8).view(-1, 4)
+    records[:, 16:] = tiles[keep]
+    return records
+
+
+def unpack_sparse_torch(frames: torch.Tensor, records: torch.Tensor, stripes) -> None:
+    """CPU form of kifs_unpack_sparse_async: records -> their rows of frames (count, H, W, 4)."""
+    count, height, width, _ = frames.shape
+    tx, ns = _tiles_x(width), len(stripes)
+    ids = records[:, :4].contiguous().view(torch.int32).flatten().tolist()
+    for rec, tid in zip(records, ids):
+        if not (0 <= tid < count * ns * tx):
+            continue
+        shard, rest = divmod(tid, ns * tx)
+        k, col = divmod(rest, tx)
+        y0, x0 = stripes[k] * STRIPE_ROWS, col * _TILE_W
+        h, w = min(STRIPE_ROWS, height - y0), min(_TILE_W, width - x0)
+        frames[shard, y0:y0 + h, x0:x0 + w] = rec[16:].view(STRIPE_ROWS, _TILE_W, 4)[:h, :w]
+
+
+def fill_stripes_torch(frames: torch.Tensor, stripes, background_rgba: int) -> None:
+    bg = torch.tensor([(background_rgba >> s) & 255 for s in (0, 8, 16, 24)], dtype=torch.uint8, device=frames.device)
+    for s in stripes:
+        frames[:, s * STRIPE_ROWS:(s + 1) * STRIPE_ROWS] = bg
+
+
+class SparseShardFrames(ShardFrames):
+    """ShardFrames whose peers send only the 32 x 8 tiles that hold something.
+
+    The root of the gather takes each peer's rows over one xGMI link (~19 Gpixel/s inbound), a GPU renders
+    several times faster, and most of a frame of these scenes is the background colour: dense shards make
+    the links the bottleneck (two GPUs slower than one unless the root renders most of the frame itself).
+    Here a peer packs its shards into records of their non-background tiles (kifs_pack_sparse_async), the
+    root fills the peers' rows with the background (kifs_fill_shard_async, on `fill_stream` beside its own
+    rendering) and scatters the received records over it (kifs_unpack_sparse_async).  Lossless: the
+    gathered frames are the single-GPU frames byte for byte, whatever they show.
+
+    Message sizes depend on the frames, and point-to-point transfers need them on the host of both sides:
+    the number of records of step k reaches the peer's host asynchronously (pinned memory), and is
+    exchanged -- one small gather over `count_group`, a CPU (gloo) group -- while step k + 1 is already
+    rendering; then the payload of step k is posted.  So transfers lag the rendering by one step, exactly as
+    the dense form's do, and nothing on the GPU waits for the host.
+
+    pack(shards, stripes, records) -> callable returning the number of records (may block until known);
+    unpack_sparse(frames, records, n, stripes); fill(frames, stripes): device forms from GraphicState
+    (bench.py) or the *_torch functions above bound to a background pixel (CPU tests)."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device, frames_per_step: int = 1,
+                 root: int = 0, buffers: int = 2, group=None, weights=None, contiguous: bool = False,
+                 pack: Callable = None, unpack_sparse: Callable = None, fill: Callable = None, count_group=None,
+                 fill_stream=None):
+        if pack is None or unpack_sparse is None or fill is None:
+            raise ValueError("SparseShardFrames: pack, unpack_sparse and fill are required")
+        if buffers < 2:
+            raise ValueError("SparseShardFrames: transfers lag the rendering by a step: at least two buffers")
+        super().__init__(width, height, rank, world, device, frames_per_step, root, buffers, group, weights, contiguous)
+        self.pack, self.unpack_sparse, self.fill = pack, unpack_sparse, fill
+        self.count_group = count_group if count_group is not None else group
+        self.fill_stream = fill_stream
+        self._count_fn = [None] * buffers     # peer: the step's record count, once the host may know it
+        self._counts = [None] * buffers       # per rank, after the exchange
+        self._slot_free = [None] * buffers    # root: the slot's frames may be overwritten (event on the render stream)
+        self._fill_done = [None] * buffers
+        self._unflushed = None                # the step whose payload has not been posted yet
+        self.records_sent = 0                 # statistics: records received and tiles they stand for
+        self.tiles_seen = 0
+
+    def _alloc_transfer_buffers(self):
+        rank, root, world, buffers, dev = self.rank, self.root, self.world, self.buffers, self.device
+        self.capacity = [self.count * len(self.stripes[r]) * _tiles_x(self.width) for r in range(world)]
+        records = lambda r, **kw: torch.empty((max(1, self.capacity[r]), SPARSE_RECORD_BYTES), dtype=torch.uint8, **kw)
+        if rank == root:
+            self._recv = [[records(r, device=dev) if r != root and self.capacity[r] else None for r in range(world)]
+                          for _ in range(buffers)]
+            self.peer_stripes = sorted(s for r in range(world) if r != root for s in self.stripes[r])
+        else:
+            self._records = [records(rank, device=dev) for _ in range(buffers)]
+        if self._staged:
+            if rank == root:
+                self._host = [[records(r) if r != root and self.capacity[r] else None for r in range(world)]
+                              for _ in range(buffers)]
+            else:
+                self._host = [records(rank) for _ in range(buffers)]
+
+    # -- the two halves of a step's gather
+    def _start_fill(self, k: int):
+        """Root, before step k's own rendering: the background under the peers' rows, on the fill stream
+        (beside the rendering: disjoint rows) once the slot's previous frames have been consumed."""
+        slot = k % self.buffers
+        if self.rank != self.root or self.world == 1 or not self.peer_stripes:
+            return
+        if self.fill_stream is not None:
+            self.fill_stream.wait_event(self._slot_free[slot] or torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(self.fill_stream):
+                self.fill(self._frames[slot], self.peer_stripes)
+                self._fill_done[slot] = self.fill_stream.record_event()
+        else:
+            self.fill(self._frames[slot], self.peer_stripes)
+
+    def _pack(self, k: int):
+        """Peer, after step k's rendering is enqueued."""
+        slot = k % self.buffers
+        if self.rank != self.root and self.rows[self.rank] > 0:
+            self._count_fn[slot] = self.pack(self._mine[slot], self.my_stripes, self._records[slot])
+
+    def _flush(self, k: int):
+        """Exchange step k's record counts (host) and post its transfers."""
+        slot = k % self.buffers
+        mine = 0
+        if self.rank != self.root and self.rows[self.rank] > 0:
+            mine = int(self._count_fn[slot]())
+        t = torch.tensor([mine], dtype=torch.int64)
+        if self.world > 1:
+            backend = dist.get_backend(self.count_group)
+            if backend == "nccl":  # no CPU group was given: the counts travel through device memory
+                every = torch.empty(self.world, dtype=torch.int64, device=self.device)
+                dist.all_gather_into_tensor(every, t.to(self.device), group=self.count_group)
+                counts = every.tolist()
+            else:
+                gathered = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)] if self.rank == self.root else None
+                dist.gather(t, gathered, dst=self.root, group=self.count_group)
+                counts = [int(g.item()) for g in gathered] if gathered else None
+        else:
+            counts = [0]
+        self._counts[slot] = counts
+        ops = []
+        if self.rank == self.root:
+            for r in range(self.world):
+                if r != self.root and counts[r] > 0:
+                    if counts[r] > self.capacity[r]:
+                        raise RuntimeError(f"SparseShardFrames: rank {r} announced {counts[r]} records, capacity {self.capacity[r]}")
+                    dst = self._host[slot][r] if self._staged else self._recv[slot][r]
+                    ops.append(dist.P2POp(dist.irecv, dst[:counts[r]], r, self.group))
+                    self.records_sent += counts[r]
+                self.tiles_seen += self.capacity[r] if r != self.root else 0
+        elif mine > 0:
+            src = self._records[slot][:mine]
+            if self._staged:
+                self._host[slot][:mine].copy_(src)
+                src = self._host[slot][:mine]
+            ops.append(dist.P2POp(dist.isend, src, self.root, self.group))
+        self._works[slot] = dist.batch_isend_irecv(ops) if ops else []
+
+    def gather_async(self, k: int):
+        """Both halves at once (tests, calibration): the host waits for step k's count."""
+        if self._unflushed is not None:
+            self._flush(self._unflushed)
+            self._unflushed = None
+        self._start_fill(k)
+        self._pack(k)
+        self._flush(k)
+
+    def wait(self, k: int):
+        slot = k % self.buffers
+        if self._unflushed is not None and self._unflushed % self.buffers == slot:
+            self._flush(self._unflushed)
+            self._unflushed = None
+        works = self._works[slot]
+        if works is not None:
+            for w in works:
+                w.wait()
+            if self.rank == self.root and self.world > 1:
+                if self._fill_done[slot] is not None:
+                    torch.cuda.current_stream().wait_event(self._fill_done[slot])
+                    self._fill_done[slot] = None
+                counts = self._counts[slot]
+                for r in range(self.world):
+                    if r != self.root and counts[r] > 0:
+                        if self._staged:
+                            self._recv[slot][r][:counts[r]].copy_(self._host[slot][r][:counts[r]])
+                        self.unpack_sparse(self._frames[slot], self._recv[slot][r], counts[r], self.stripes[r])
+                if self.fill_stream is not None:
+                    self._slot_free[slot] = torch.cuda.current_stream().record_event()
+        self._works[slot] = None
+
+    def wait_all(self):
+        if self._unflushed is not None:
+            self._flush(self._unflushed)
+            self._unflushed = None
+        for slot in range(self.buffers):
+            self.wait(slot)
+
+    def step(self, k: int, render_shard: Callable):
+        self.wait(k)
+        self._start_fill(k)
+        if self.rows[self.rank] > 0:
+            outs, in_place = self.targets(k)
+            render_shard(outs, k * self.count, self.my_stripes, in_place)
+        self._pack(k)
+        if self._unflushed is not None:  # step k - 1: its count has had a whole step to reach the host
+            self._flush(self._unflushed)
+        self._unflushed = k

@@ -420,6 +420,25 @@ int residency_for(const kifs::FrameParams& P, uint32_t group, double heavy_tiles
     return 0;
 }
 
+// The background pixel, encoded exactly as the kernels would (unorm8 / srgb8 of kifs_device_math.hpp).
+uint32_t background_pixel(const kifs_ctx* c, kifs::V3 colour, int encode) {
+    uint32_t ch[3];
+    const float bg[3] = {colour.x, colour.y, colour.z};
+    for (int i = 0; i < 3; ++i) {
+        const float x = bg[i];
+        if (encode == KIFS_ENCODE_SRGB) {
+            uint32_t k = 0;
+            for (uint32_t step = 128; step >= 1; step >>= 1) k += (x >= c->h_srgb[k + step]) ? step : 0u;
+            ch[i] = k;
+        } else {
+            float v = (x >= 0.0f) ? x : 0.0f;
+            v = (v > 1.0f) ? 1.0f : v;
+            ch[i] = uint32_t(int(v * 255.0f + 0.5f));
+        }
+    }
+    return ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
+}
+
 // One launch: `count` frames (count == 1: the context's camera; count > 1: cameras[i] -> outs[i])
 // sharing everything else.
 // `stripes` non-null: the launch renders that row shard (y0 = 0, y1 = height) instead of a band, into
@@ -467,23 +486,7 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     P.y0 = y0;
     P.y1 = y1;
     P.encode = encode;
-    {   // the background pixel, encoded exactly as the kernels would (unorm8 / srgb8 of kifs_device_math.hpp)
-        uint32_t ch[3];
-        const float bg[3] = {P.background_color.x, P.background_color.y, P.background_color.z};
-        for (int i = 0; i < 3; ++i) {
-            const float x = bg[i];
-            if (encode == KIFS_ENCODE_SRGB) {
-                uint32_t k = 0;
-                for (uint32_t step = 128; step >= 1; step >>= 1) k += (x >= c->h_srgb[k + step]) ? step : 0u;
-                ch[i] = k;
-            } else {
-                float v = (x >= 0.0f) ? x : 0.0f;
-                v = (v > 1.0f) ? 1.0f : v;
-                ch[i] = uint32_t(int(v * 255.0f + 0.5f));
-            }
-        }
-        P.background_rgba = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
-    }
+    P.background_rgba = background_pixel(c, P.background_color, encode);
     P.pitch_words = uint32_t(pitch >> 2);
     P.out = reinterpret_cast<uint32_t*>(dev_out);
     if (y1 == y0) return KIFS_OK;
@@ -870,6 +873,98 @@ int kifs_unpack_shard_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* d
     return hip_ok(kifs::launch_unpack_stripes(dev_frames, frame_pitch, frame_stride, dev_shards, shard_pitch,
                                               shard_stride, rows->d_rows, n_stripes, count, w, h, s),
                   "unpack_stripes_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+// ---- sparse shards ---------------------------------------------------------------------------
+namespace {
+// what the three entry points share: the frame's size, the stripes' row table, the background pixel
+int sparse_setup(kifs_ctx* c, const int* stripes, int n_stripes, int encode, int* w, int* h, const RowTable** rows,
+                 uint32_t* background) {
+    if (!c->have_screen || (background && !c->have_options)) return KIFS_ERR_UNCONFIGURED;
+    int st = frame_dims(c, w, h);
+    if (st != KIFS_OK) return st;
+    if (background) {
+        if (encode != KIFS_ENCODE_UNORM && encode != KIFS_ENCODE_SRGB) return KIFS_ERR_BAD_ARG;
+        const float* bc = c->options.background_color;
+        *background = background_pixel(c, kifs::V3{bc[0], bc[1], bc[2]}, encode);
+    }
+    *rows = row_table(c, stripes, n_stripes, *h);
+    return *rows ? KIFS_OK : KIFS_ERR_BAD_ARG;
+}
+}  // namespace
+
+int kifs_pack_sparse_async(kifs_ctx* c, void* hip_stream, int count, const uint8_t* dev_shards, size_t shard_pitch,
+                           size_t shard_stride, const int* stripes, int n_stripes, int encode, uint8_t* dev_records,
+                           size_t capacity_records, uint32_t* dev_n_records, uint32_t* host_n_records) {
+    if (!c || !dev_shards || !stripes || !dev_records || !dev_n_records || n_stripes < 0 || count < 0) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    int w = 0, h = 0;
+    const RowTable* rows = nullptr;
+    uint32_t background = 0;
+    if (n_stripes == 0 || count == 0) {
+        if (!c->have_screen || !c->have_options) return KIFS_ERR_UNCONFIGURED;
+    } else {
+        int st = sparse_setup(c, stripes, n_stripes, encode, &w, &h, &rows, &background);
+        if (st != KIFS_OK) return st;
+        const size_t tiles = size_t(count) * size_t(n_stripes) * size_t((w + kifs::TILE_W - 1) / kifs::TILE_W);
+        if (shard_pitch < size_t(w) * 4 || ((shard_pitch | shard_stride) & 3u) || capacity_records < tiles ||
+            tiles > 0xffffffffull || (reinterpret_cast<uintptr_t>(dev_shards) & 3u) ||
+            (reinterpret_cast<uintptr_t>(dev_records) & 15u) || (reinterpret_cast<uintptr_t>(dev_n_records) & 3u))
+            return KIFS_ERR_BAD_SIZE;
+    }
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    if (!hip_ok(hipMemsetAsync(dev_n_records, 0, sizeof(uint32_t), s), "memset(n_records)")) return KIFS_ERR_RUNTIME;
+    if (rows && !hip_ok(kifs::launch_pack_sparse(dev_shards, shard_pitch, shard_stride, rows->d_rows, n_stripes, count, w, h,
+                                                 background, reinterpret_cast<uint32_t*>(dev_records), dev_n_records, s),
+                        "pack_sparse_kernel launch"))
+        return KIFS_ERR_RUNTIME;
+    if (host_n_records &&
+        !hip_ok(hipMemcpyAsync(host_n_records, dev_n_records, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "copy(n_records)"))
+        return KIFS_ERR_RUNTIME;
+    return KIFS_OK;
+}
+
+int kifs_unpack_sparse_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch,
+                             size_t frame_stride, const uint8_t* dev_records, size_t n_records, const int* stripes,
+                             int n_stripes) {
+    if (!c || !dev_frames || !stripes || n_stripes < 0 || count < 0 || (n_records && !dev_records)) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    if (!c->have_screen) return KIFS_ERR_UNCONFIGURED;
+    if (n_stripes == 0 || count == 0 || n_records == 0) return KIFS_OK;
+    int w = 0, h = 0;
+    const RowTable* rows = nullptr;
+    int st = sparse_setup(c, stripes, n_stripes, 0, &w, &h, &rows, nullptr);
+    if (st != KIFS_OK) return st;
+    const size_t tiles = size_t(count) * size_t(n_stripes) * size_t((w + kifs::TILE_W - 1) / kifs::TILE_W);
+    if (frame_pitch < size_t(w) * 4 || ((frame_pitch | frame_stride) & 3u) || n_records > tiles ||
+        (reinterpret_cast<uintptr_t>(dev_frames) & 3u) || (reinterpret_cast<uintptr_t>(dev_records) & 15u))
+        return KIFS_ERR_BAD_SIZE;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return hip_ok(kifs::launch_unpack_sparse(dev_frames, frame_pitch, frame_stride, reinterpret_cast<const uint32_t*>(dev_records),
+                                             uint32_t(n_records), rows->d_rows, n_stripes, count, w, h, s),
+                  "unpack_sparse_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+int kifs_fill_shard_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch,
+                          size_t frame_stride, const int* stripes, int n_stripes, int encode) {
+    if (!c || !dev_frames || !stripes || n_stripes < 0 || count < 0) return KIFS_ERR_BAD_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    if (!c->have_screen || !c->have_options) return KIFS_ERR_UNCONFIGURED;
+    if (n_stripes == 0 || count == 0) return KIFS_OK;
+    int w = 0, h = 0;
+    const RowTable* rows = nullptr;
+    uint32_t background = 0;
+    int st = sparse_setup(c, stripes, n_stripes, encode, &w, &h, &rows, &background);
+    if (st != KIFS_OK) return st;
+    if (frame_pitch < size_t(w) * 4 || ((frame_pitch | frame_stride) & 3u) || (reinterpret_cast<uintptr_t>(dev_frames) & 3u))
+        return KIFS_ERR_BAD_SIZE;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return hip_ok(kifs::launch_fill_stripes(dev_frames, frame_pitch, frame_stride, rows->d_rows, n_stripes, count, w, h,
+                                            background, s),
+                  "fill_stripes_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;
 }
 
 int kifs_render_async(kifs_ctx* c, void* hip_stream, uint8_t* dev_out, size_t pitch, int y0,

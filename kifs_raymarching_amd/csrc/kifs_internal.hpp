@@ -18,6 +18,18 @@ hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t tile_coun
 hipError_t launch_unpack_stripes(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint8_t* src,
                                  size_t src_pitch, size_t src_shard_stride, const uint32_t* stripe_rows,
                                  int n_stripes, int count, int width, int height, hipStream_t stream);
+// Sparse shards (see pack_sparse_kernel): records of SPARSE_RECORD_WORDS words for the tiles of packed shards
+// that hold a pixel other than `background`; *n_records must be zero beforehand.  And back: records -> frame
+// rows; the background over the rows of the listed stripes.
+constexpr int SPARSE_RECORD_WORDS_HOST = 260;
+hipError_t launch_pack_sparse(const uint8_t* src, size_t src_pitch, size_t src_shard_stride, const uint32_t* stripe_rows,
+                              int n_stripes, int count, int width, int height, uint32_t background, uint32_t* records,
+                              uint32_t* n_records, hipStream_t stream);
+hipError_t launch_unpack_sparse(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint32_t* records,
+                                uint32_t n_records, const uint32_t* stripe_rows, int n_stripes, int count, int width,
+                                int height, hipStream_t stream);
+hipError_t launch_fill_stripes(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint32_t* stripe_rows,
+                               int n_stripes, int count, int width, int height, uint32_t background, hipStream_t stream);
 hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,
                               const float* pts, int n, float* sdf, float* nrm,
                               hipStream_t stream);

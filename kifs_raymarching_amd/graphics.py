@@ -20,6 +20,7 @@ import numpy as np
 from . import _lib
 
 MAX_BATCH = 64  # KIFS_MAX_BATCH of include/kifs_hip.h
+SPARSE_RECORD_BYTES = 1040  # KIFS_SPARSE_RECORD_BYTES
 STRIPE_ROWS = 8  # KIFS_STRIPE_ROWS
 from ._lib import (CameraDataC, CameraUniform, ExtensionsC, GuiDataC, KifsError, OptionsUniform,
                    ScreenUniform, check, lib)
@@ -352,6 +353,72 @@ class GraphicState:
         check(lib.kifs_unpack_shard_async(self._ctx, stream, count, _device_pointer(frames), w * 4, h * w * 4,
                                           _device_pointer(shards), w * 4, rows * w * 4, st, len(st)),
               "unpack_shard_async")
+
+    # ---- sparse shards (kifs_pack_sparse_async / kifs_unpack_sparse_async / kifs_fill_shard_async)
+    def _stream_handle(self, stream, what):
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+            if not stream:
+                raise ValueError(f"{what}: pass a non-default torch.cuda.Stream")
+        return stream
+
+    def sparse_capacity(self, count: int, stripes) -> int:
+        """Records a payload must have room for: every tile of `count` shards of these stripes."""
+        return count * len(stripes) * ((self.screen_data.width + 31) // 32)
+
+    def pack_sparse_async(self, shards, stripes, records, n_records, host_n_records=None, stream=None,
+                          encode: int = ENCODE_SRGB):
+        """Peer side: `shards` (count, rows, W, 4) packed -> `records` (capacity, 1040) uint8 device tensor,
+        their number in `n_records` (int32 device tensor of one element) and, asynchronously, in the pinned
+        host tensor `host_n_records` (valid once the stream has passed this point)."""
+        w, h = self.screen_data.width, self.screen_data.height
+        if shards.dim() != 4 or not shards.is_contiguous() or shards.element_size() != 1:
+            raise ValueError("pack_sparse_async: shards (count, rows, W, 4) uint8, contiguous")
+        count, rows = int(shards.shape[0]), int(shards.shape[1])
+        want_rows = sum(min(STRIPE_ROWS, h - s * STRIPE_ROWS) for s in stripes)
+        if tuple(shards.shape) != (count, rows, w, 4) or rows != want_rows:
+            raise ValueError(f"pack_sparse_async: shape {tuple(shards.shape)} is not {count} shards of {want_rows} x {w}")
+        if (records.dim() != 2 or int(records.shape[1]) != SPARSE_RECORD_BYTES or records.element_size() != 1
+                or not records.is_contiguous() or int(records.shape[0]) < self.sparse_capacity(count, stripes)):
+            raise ValueError(f"pack_sparse_async: records must be (>= {self.sparse_capacity(count, stripes)}, "
+                             f"{SPARSE_RECORD_BYTES}) uint8, contiguous")
+        if n_records.numel() != 1 or n_records.element_size() != 4:
+            raise ValueError("pack_sparse_async: n_records is one 32-bit integer on the device")
+        if host_n_records is not None and (host_n_records.numel() != 1 or host_n_records.element_size() != 4
+                                           or not host_n_records.is_pinned()):
+            raise ValueError("pack_sparse_async: host_n_records is one 32-bit integer in pinned host memory")
+        st = _stripe_array(stripes)
+        check(lib.kifs_pack_sparse_async(self._ctx, self._stream_handle(stream, "pack_sparse_async"), count,
+                                         _device_pointer(shards), w * 4, rows * w * 4, st, len(st), encode,
+                                         _device_pointer(records), int(records.shape[0]), _device_pointer(n_records),
+                                         _device_pointer(host_n_records) if host_n_records is not None else None),
+              "pack_sparse_async")
+
+    def unpack_sparse_async(self, frames, records, n_records: int, stripes, stream=None):
+        """Root side: the first `n_records` records of `records` -> their rows of `frames` (count, H, W, 4)."""
+        w, h = self.screen_data.width, self.screen_data.height
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (h, w, 4) or not frames.is_contiguous() or frames.element_size() != 1:
+            raise ValueError(f"unpack_sparse_async: frames (count, {h}, {w}, 4) uint8, contiguous")
+        count = int(frames.shape[0])
+        if n_records < 0 or n_records > self.sparse_capacity(count, stripes) or (n_records and (
+                records.dim() != 2 or int(records.shape[1]) != SPARSE_RECORD_BYTES or int(records.shape[0]) < n_records
+                or not records.is_contiguous() or records.element_size() != 1)):
+            raise ValueError("unpack_sparse_async: n_records records of 1040 bytes, at most one per tile of the shards")
+        st = _stripe_array(stripes)
+        check(lib.kifs_unpack_sparse_async(self._ctx, self._stream_handle(stream, "unpack_sparse_async"), count,
+                                           _device_pointer(frames), w * 4, h * w * 4,
+                                           _device_pointer(records) if n_records else None, n_records, st, len(st)),
+              "unpack_sparse_async")
+
+    def fill_shard_async(self, frames, stripes, stream=None, encode: int = ENCODE_SRGB):
+        """The background over the rows of `stripes` of `frames` (count, H, W, 4)."""
+        w, h = self.screen_data.width, self.screen_data.height
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (h, w, 4) or not frames.is_contiguous() or frames.element_size() != 1:
+            raise ValueError(f"fill_shard_async: frames (count, {h}, {w}, 4) uint8, contiguous")
+        st = _stripe_array(stripes)
+        check(lib.kifs_fill_shard_async(self._ctx, self._stream_handle(stream, "fill_shard_async"), int(frames.shape[0]),
+                                        _device_pointer(frames), w * 4, h * w * 4, st, len(st), encode),
+              "fill_shard_async")
 
     def debug_last_round_steps(self) -> int:
         """Round length of the ray re-queuing in the latest launch (0: one wave per block)."""

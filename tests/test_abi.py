@@ -22,6 +22,7 @@ def test_header_declares_the_expected_surface():
     for must in ("kifs_create", "kifs_destroy", "kifs_set_screen", "kifs_set_camera",
                  "kifs_set_options", "kifs_set_iters", "kifs_render", "kifs_render_async",
                  "kifs_band_range", "kifs_shard_stripes", "kifs_render_shard_async", "kifs_unpack_shard_async",
+                 "kifs_pack_sparse_async", "kifs_unpack_sparse_async", "kifs_fill_shard_async",
                  "kifs_render_batch_async", "kifs_last_kernel_ms", "kifs_strerror", "kifs_host_camera",
                  "kifs_host_options", "kifs_host_screen", "kifs_eval_points", "kifs_eval_math"):
         assert must in names
@@ -84,6 +85,9 @@ def test_null_and_bad_arguments_do_not_crash(kifs):
     assert lib.kifs_render_async(None, None, None, 0, 0, 0, 1) == 7
     assert lib.kifs_render_shard_async(None, None, 1, None, None, 0, None, 0, 0, 1) == 7
     assert lib.kifs_unpack_shard_async(None, None, 1, None, 0, 0, None, 0, 0, None, 0) == 7
+    assert lib.kifs_pack_sparse_async(None, None, 1, None, 0, 0, None, 0, 1, None, 0, None, None) == 7
+    assert lib.kifs_unpack_sparse_async(None, None, 1, None, 0, 0, None, 0, None, 0) == 7
+    assert lib.kifs_fill_shard_async(None, None, 1, None, 0, 0, None, 0, 1) == 7
     n = C.c_int()
     assert lib.kifs_shard_stripes(8, 2, None, 0, None, 0, None, None) == 7          # nowhere to report the count
     assert lib.kifs_shard_stripes(64, 2, None, 0, None, 0, C.byref(n), None) == 0 and n.value == 4  # counting only

@@ -200,20 +200,35 @@ def _oracle_rows(O, sc, cam, opt, it, height, stripes):
     return np.concatenate(parts, axis=0)
 
 
-def _shard_worker(rank, world, port, width, height, steps, count, weights, contiguous, outdir):
+def _shard_worker(rank, world, port, width, height, steps, count, weights, contiguous, outdir, sparse=False):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import oracle as O
-        from kifs_raymarching_amd.bands import ShardFrames
+        from kifs_raymarching_amd import bands
+        from kifs_raymarching_amd.bands import ShardFrames, SparseShardFrames
 
         sc = O.screen_uniform(width, height)
         opt = O.options_from_gui(fractal_group=1, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=40)
         it = O.iters(8, 4, 4)
-        sf = ShardFrames(width, height, rank, world, "cpu", frames_per_step=count, weights=weights,
-                         contiguous=contiguous)
+        if sparse:
+            # the background pixel as the renderer encodes it: the corner of a frame seen from far away
+            far = O.render(sc, O.camera_uniform(50.0, 0.0, 0.0), opt, it, y0=0, y1=1, nthreads=1)[0, 0]
+            bg = int(far[0]) | int(far[1]) << 8 | int(far[2]) << 16 | int(far[3]) << 24
+
+            def pack(shards, stripes, records):
+                r = bands.pack_sparse_torch(shards, stripes, height, bg)
+                records[:r.shape[0]].copy_(r)
+                return lambda: r.shape[0]
+            sf = SparseShardFrames(width, height, rank, world, "cpu", frames_per_step=count, weights=weights,
+                                   contiguous=contiguous, pack=pack,
+                                   unpack_sparse=lambda frames, records, n, stripes: bands.unpack_sparse_torch(frames, records[:n], stripes),
+                                   fill=lambda frames, stripes: bands.fill_stripes_torch(frames, stripes, bg))
+        else:
+            sf = ShardFrames(width, height, rank, world, "cpu", frames_per_step=count, weights=weights,
+                             contiguous=contiguous)
         every = sorted(s for st in sf.stripes for s in st)
         assert every == list(range((height + 7) // 8)), "every stripe is dealt exactly once"
 
@@ -242,23 +257,29 @@ def _shard_worker(rank, world, port, width, height, steps, count, weights, conti
         if rank == 0:
             got.append(sf.frames(steps - 1).clone().numpy())
             np.save(os.path.join(outdir, "shards.npy"), np.concatenate(got, axis=0))
+            if sparse:
+                np.save(os.path.join(outdir, "sparse_stats.npy"), np.array([sf.records_sent, sf.tiles_seen]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,count,weights,contiguous", [
-    (2, 40, 2, None, False),       # 5 stripes over 2 ranks: 3 + 2
-    (3, 43, 2, None, False),       # 6 stripes, the last one 3 rows tall
-    (3, 52, 1, [3, 1, 1], False),  # a root that renders three stripes in five
-    (2, 44, 2, None, True),        # contiguous runs of stripes through the same machinery
+@pytest.mark.parametrize("world,height,count,weights,contiguous,sparse,width", [
+    (2, 40, 2, None, False, False, 40),       # 5 stripes over 2 ranks: 3 + 2
+    (3, 43, 2, None, False, False, 40),       # 6 stripes, the last one 3 rows tall
+    (3, 52, 1, [3, 1, 1], False, False, 40),  # a root that renders three stripes in five
+    (2, 44, 2, None, True, False, 40),        # contiguous runs of stripes through the same machinery
+    (2, 40, 2, None, False, True, 100),       # sparse shards: only the tiles that hold something travel
+    (3, 43, 2, None, False, True, 72),        # ... ragged tiles at the right and bottom edges
+    (3, 52, 1, [1, 2, 2], False, True, 96),   # ... a root with the smaller share
 ])
-def test_shard_gather_equals_single_frames(world, height, count, weights, contiguous, tmp_path, oracle):
+def test_shard_gather_equals_single_frames(world, height, count, weights, contiguous, sparse, width, tmp_path, oracle):
     """bench.py's default at N > 1: every rank renders its stripes of the step's frames, one message
-    per peer, the root unpacks; the gathered frames equal single-process frames."""
-    width, steps = 40, 3
+    per peer (dense rows, or records of the non-background tiles with the sizes exchanged a step behind),
+    the root unpacks; the gathered frames equal single-process frames."""
+    steps = 4 if sparse else 3
     mp.spawn(_shard_worker,
-             args=(world, _free_port(), width, height, steps, count, weights, contiguous, str(tmp_path)),
+             args=(world, _free_port(), width, height, steps, count, weights, contiguous, str(tmp_path), sparse),
              nprocs=world, join=True)
     got = np.load(tmp_path / "shards.npy")
     assert got.shape == (steps * count, height, width, 4)
@@ -268,6 +289,40 @@ def test_shard_gather_equals_single_frames(world, height, count, weights, contig
         want = oracle.render(sc, oracle.camera_uniform(3.0, 0.3 * f, 0.1), opt, oracle.iters(8, 4, 4))
         assert (got[f] == want).all(), f"frame {f} differs"
     assert (got[0] != got[1]).any()
+    if sparse:
+        sent, seen = np.load(tmp_path / "sparse_stats.npy")
+        assert 0 < sent < seen, "some tiles travelled, the background ones did not"
+
+
+def test_sparse_records_round_trip():
+    """pack_sparse_torch / unpack_sparse_torch / fill_stripes_torch (the CPU forms of the library's kernels):
+    a frame's stripes -> records -> the frame again, for ragged widths and heights; all-background shards make
+    no records, a shard without background one per tile."""
+    from kifs_raymarching_amd import bands
+    rng = np.random.default_rng(5)
+    bg = 0xff332211
+    bg_px = np.array([0x11, 0x22, 0x33, 0xff], dtype=np.uint8)
+    for (W, H, count) in ((100, 43, 2), (64, 16, 1), (33, 9, 3)):
+        frames = np.broadcast_to(bg_px, (count, H, W, 4)).copy()
+        for _ in range(6):  # a few blobs
+            f, y, x = rng.integers(count), rng.integers(H), rng.integers(W)
+            frames[f, y:y + rng.integers(1, 12), x:x + rng.integers(1, 40)] = rng.integers(0, 255, 4, dtype=np.uint8)
+        n_stripes = (H + 7) // 8
+        stripes = [s for s in range(n_stripes) if s % 2 == 0]
+        rows = [y for s in stripes for y in range(8 * s, min(H, 8 * s + 8))]
+        shards = torch.from_numpy(frames[:, rows])
+        rec = bands.pack_sparse_torch(shards, stripes, H, bg)
+        tiles = count * len(stripes) * ((W + 31) // 32)
+        assert rec.shape[1] == 1040 and 0 < rec.shape[0] <= tiles
+        out = torch.zeros((count, H, W, 4), dtype=torch.uint8)
+        bands.fill_stripes_torch(out, stripes, bg)
+        bands.unpack_sparse_torch(out, rec, stripes)
+        assert (out.numpy()[:, rows] == frames[:, rows]).all()
+        other = [y for y in range(H) if y not in rows]
+        assert (out.numpy()[:, other] == 0).all()          # rows of other stripes untouched
+        assert bands.pack_sparse_torch(torch.from_numpy(np.broadcast_to(bg_px, shards.shape).copy()), stripes, H, bg).shape[0] == 0
+        full = torch.from_numpy(rng.integers(0, 200, shards.shape, dtype=np.uint8))
+        assert bands.pack_sparse_torch(full, stripes, H, bg).shape[0] == tiles
 
 
 def test_shard_stripes_partition(kifs):

@@ -350,3 +350,81 @@ def test_tile_level_exit_with_odd_cameras(gs, kifs, oracle):
         c = oracle.from_bytes(oracle.Camera, kifs.uniform_bytes(cams2[k]))
         want = oracle.render(s, c, o, oracle.iters(*w.iters), encode=1)
         assert (got[k] == want).all(), (k, int((got[k] != want).any(-1).sum()))
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (1000, 530)])
+def test_sparse_shards_on_the_gpu(size, gs, kifs, oracle):
+    """kifs_pack_sparse_async / kifs_unpack_sparse_async / kifs_fill_shard_async against their CPU forms
+    (bands.pack_sparse_torch ..): rank 1 of 3's shards of four orbit frames -> records (the same set, in any
+    order) -> background-filled frames == the frames' rows; ragged tiles at the right and bottom edges; a
+    frame with no background at all; argument checks."""
+    import torch
+    from kifs_raymarching_amd import bands
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+    w = WORKLOADS["cfg2_julia_1080p"]
+    W, H = size
+    gs.update_screen_data(kifs.ScreenData(W, H))
+    gs.update_options(w.gui)
+    gs.set_iters(*w.iters)
+    stripes, rows = kifs.shard_stripes(H, 1, 3)
+    cams = [orbit_camera(w, 5 * k) for k in range(4)]
+    stream = torch.cuda.Stream()
+    shards = torch.zeros((4, rows, W, 4), dtype=torch.uint8, device="cuda:0")
+    gs.render_shard_async([shards[i] for i in range(4)], cams, stripes, stream=stream)
+    cap = gs.sparse_capacity(4, stripes)
+    assert cap == 4 * len(stripes) * ((W + 31) // 32)
+    records = torch.zeros((cap, 1040), dtype=torch.uint8, device="cuda:0")
+    n_dev = torch.full((1,), 77, dtype=torch.int32, device="cuda:0")
+    n_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    gs.pack_sparse_async(shards, stripes, records, n_dev, n_host, stream=stream)
+    stream.synchronize()
+    n = int(n_host[0])
+    assert n == int(n_dev.cpu()[0]) and 0 < n < cap // 3, "most of these frames is background"
+    far = oracle_frame(oracle, kifs, kifs.ScreenData(64, 8), kifs.CameraData(origin_distance=50.0), w.gui, w.iters)[0, 0]
+    bg = int(far[0]) | int(far[1]) << 8 | int(far[2]) << 16 | int(far[3]) << 24
+    want = bands.pack_sparse_torch(shards.cpu(), stripes, H, bg)
+    got = records[:n].cpu()
+    order = torch.argsort(got[:, :4].contiguous().view(torch.int32).flatten())
+    assert want.shape[0] == n and (got[order] == want).all()
+    # the root's side: background under the stripes, records over it
+    frames = torch.zeros((4, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    gs.fill_shard_async(frames, stripes, stream=stream)
+    gs.unpack_sparse_async(frames, records, n, stripes, stream=stream)
+    stream.synchronize()
+    ys = [y for s in stripes for y in range(8 * s, min(H, 8 * s + 8))]
+    assert (frames[:, ys] == shards).all()
+    others = [y for y in range(H) if y not in set(ys)]
+    assert int(frames[:, others].max()) == 0, "rows of other ranks' stripes are not touched"
+    # a shard with no background: one record per tile; an all-background one: none
+    noise = torch.randint(0, 200, shards.shape, dtype=torch.uint8, device="cuda:0")
+    gs.pack_sparse_async(noise, stripes, records, n_dev, n_host, stream=stream)
+    stream.synchronize()
+    assert int(n_host[0]) == cap
+    frames.zero_()
+    gs.unpack_sparse_async(frames, records, cap, stripes, stream=stream)
+    stream.synchronize()
+    assert (frames[:, ys] == noise).all()
+    blank = torch.zeros_like(shards)
+    blank[...] = torch.tensor([(bg >> s) & 255 for s in (0, 8, 16, 24)], dtype=torch.uint8, device="cuda:0")
+    gs.pack_sparse_async(blank, stripes, records, n_dev, n_host, stream=stream)
+    stream.synchronize()
+    assert int(n_host[0]) == 0
+    gs.unpack_sparse_async(frames, records, 0, stripes, stream=stream)  # nothing to do is fine
+    # argument checks
+    with pytest.raises(ValueError):
+        gs.pack_sparse_async(shards, stripes, records[:cap - 1], n_dev, n_host, stream=stream)   # no room for every tile
+    with pytest.raises(ValueError):
+        gs.pack_sparse_async(shards[:, :-1], stripes, records, n_dev, n_host, stream=stream)     # rows do not match the stripes
+    with pytest.raises(ValueError):
+        gs.pack_sparse_async(shards, stripes, records, n_dev, torch.zeros(1, dtype=torch.int32), stream=stream)  # not pinned
+    with pytest.raises(ValueError):
+        gs.unpack_sparse_async(frames, records, cap + 1, stripes, stream=stream)
+    with pytest.raises(ValueError):
+        gs.fill_shard_async(frames[:, :-1], stripes, stream=stream)
+    # ids that do not belong to the shard are skipped, not written somewhere
+    bad = records[:2].clone()
+    bad[:, :4] = 255
+    frames.zero_()
+    gs.unpack_sparse_async(frames, bad, 2, stripes, stream=stream)
+    stream.synchronize()
+    assert int(frames.max()) == 0
