@@ -277,8 +277,20 @@ def main():
     buffers = F if F >= 2 else 2  # buffer slot k % buffers always belongs to stream k % F
     B = max(1, min(args.frames_per_launch, K.MAX_BATCH))
 
+    # The orbit's poses as uniform images, made once; a step's camera array is cached by where in the orbit it
+    # starts (a step of a few hundred views would otherwise spend a GPU step's time preparing them on the host).
+    pose_images = {"orbit": [orbit_camera(w, i).into_buffer_data() for i in range(orbit_len)],
+                   "fixed": [w.camera.into_buffer_data()]}
+    camera_arrays = {}
+
     def cameras(first, n, mode):
-        return [orbit_camera(w, (first + i) % orbit_len) if mode == "orbit" else w.camera for i in range(n)]
+        poses = pose_images["orbit" if mode == "orbit" else "fixed"]
+        key_ = (mode, first % len(poses), n)
+        if key_ not in camera_arrays:
+            if len(camera_arrays) > 64:
+                camera_arrays.clear()
+            camera_arrays[key_] = K.camera_array([poses[(first + i) % len(poses)] for i in range(n)])
+        return camera_arrays[key_]
 
     def barrier():
         if world > 1:
@@ -324,7 +336,7 @@ def main():
             g, st = gss[cur[0]], streams[cur[0]]
             cams = cameras(step_index * b, b, camera_mode)
             if b == 1:
-                g.set_camera(cams[0])  # the reference's per-frame uniform upload (render.rs:320-321)
+                g.set_raw_uniforms(camera=cams[0])  # the reference's per-frame uniform upload (render.rs:320-321)
                 g.render_async(out, stream=st, y0=0, y1=H, encode=args.encode)
             else:
                 g.render_batch_async([out[i * H:(i + 1) * H] for i in range(b)], cams, stream=st,
@@ -373,9 +385,15 @@ def main():
 
         def render(outs, first_frame, stripes, in_place):
             cams = cameras(first_frame, len(outs), camera_mode)
+            if len(outs) <= K.MAX_BATCH:  # one launch: prepared pointer and camera arrays as they are
+                gs.render_shard_async(outs, cams, stripes, in_place=in_place, stream=streams[0], encode=args.encode)
+                return
             for a in range(0, len(outs), K.MAX_BATCH):
                 gs.render_shard_async(outs[a:a + K.MAX_BATCH], cams[a:a + K.MAX_BATCH], stripes,
                                       in_place=in_place, stream=streams[0], encode=args.encode)
+
+        if frames_per_step <= K.MAX_BATCH:
+            sf.wrap_targets = K.DevicePointers  # a slot's destination pointers, collected once
 
         def step(k):
             with torch.cuda.stream(streams[0]):
@@ -457,7 +475,7 @@ def main():
             ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
 
             def single(frame_index):
-                gs.set_camera(cameras(frame_index, 1, args.camera)[0])
+                gs.set_raw_uniforms(camera=cameras(frame_index, 1, args.camera)[0])
                 gs.render(out=ref, encode=args.encode)
                 return ref
             if sharded:

@@ -170,7 +170,7 @@ int kifs_render_async(kifs_ctx* ctx, void* hip_stream, uint8_t* dev_out_rgba8,
  * idle -- its run time is the critical path of a few long rays -- and the workgroups of a batch
  * are interleaved frame by frame, so the long rays of all its frames march side by side.
  * Every frame is bit-identical to the same frame rendered alone. */
-#define KIFS_MAX_BATCH 64
+#define KIFS_MAX_BATCH 512
 int kifs_render_batch_async(kifs_ctx* ctx, void* hip_stream, int count,
                             const KifsCameraUniform* cameras, uint8_t* const* dev_outs_rgba8,
                             size_t pitch_bytes, int y0, int y1, int encode);

@@ -8,9 +8,9 @@ no CPU or PyTorch fallback for the render path.
 """
 from . import _lib  # noqa: F401  (raises ImportError when the HIP library is absent)
 from ._lib import ENCODE_SRGB, ENCODE_UNORM, KifsError
-from .graphics import (MAX_BATCH, CameraData, FractalGroup, GraphicState, GuiData, MultiGraphicState,
+from .graphics import (MAX_BATCH, CameraData, DevicePointers, camera_array, FractalGroup, GraphicState, GuiData, MultiGraphicState,
                        PrimitiveShape, ScreenData, band_range, shard_stripes, uniform_bytes)
 
 __all__ = ["GraphicState", "MultiGraphicState", "ScreenData", "CameraData", "GuiData", "FractalGroup",
            "PrimitiveShape", "KifsError", "ENCODE_SRGB", "ENCODE_UNORM", "band_range",
-           "uniform_bytes", "MAX_BATCH", "shard_stripes"]
+           "uniform_bytes", "MAX_BATCH", "shard_stripes", "DevicePointers", "camera_array"]

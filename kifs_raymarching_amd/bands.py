@@ -277,6 +277,8 @@ class ShardFrames:
             self._frames = [None] * buffers
             self._mine = [torch.zeros(shape(rank), dtype=torch.uint8, device=self.device) for _ in range(buffers)]
         self._works: List[Optional[list]] = [None] * buffers
+        self._targets = [None] * buffers
+        self.wrap_targets = lambda outs: outs  # e.g. graphics.DevicePointers: the pointers collected once per slot
         self._staged = (world > 1 and self.device.type == "cuda"
                         and dist.get_backend(group) == "gloo")  # rehearsal on one GPU, see BandFrame
         self._alloc_transfer_buffers()
@@ -303,9 +305,10 @@ class ShardFrames:
         """(tensors to render frame 0..count-1 of step k into, in_place): the root renders into its
         frames at the rows' frame positions, a peer into its packed shards."""
         slot = k % self.buffers
-        if self.rank == self.root:
-            return [self._frames[slot][i] for i in range(self.count)], True
-        return [self._mine[slot][i] for i in range(self.count)], False
+        if self._targets[slot] is None:  # the same tensors every time the slot comes round
+            src = self._frames[slot] if self.rank == self.root else self._mine[slot]
+            self._targets[slot] = self.wrap_targets([src[i] for i in range(self.count)])
+        return self._targets[slot], self.rank == self.root
 
     def frames(self, k: int) -> Optional[torch.Tensor]:
         """(count, H, W, 4): the gathered frames of step k on the root (valid after wait(k))."""

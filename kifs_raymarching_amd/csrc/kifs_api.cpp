@@ -89,6 +89,14 @@ struct kifs_ctx {
     bool timing_pending = false;
     unsigned long long* d_counters = nullptr;  // diagnostics buffer, see FrameParams
     size_t counter_words = 0;
+    // View tables of batches beyond MAX_BATCH_INLINE: a ring of device tables, each with its pinned host
+    // image and an event recorded after the launch that read it (allocated on first use).
+    static constexpr int VIEW_RING = 4;
+    kifs::BatchView* d_views[VIEW_RING] = {};
+    kifs::BatchView* h_views[VIEW_RING] = {};
+    hipEvent_t views_used[VIEW_RING] = {};
+    bool views_busy[VIEW_RING] = {};
+    int view_slot = 0;
 };
 
 namespace {
@@ -458,9 +466,27 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     int st = fill_params(c, &P);
     if (st != KIFS_OK) return st;
     B.count = count;
+    B.table = nullptr;
+    // a batch beyond the kernel argument's room: the views go through a device table (ring slot `vs`)
+    const bool big = count > kifs::MAX_BATCH_INLINE;
+    int vs = -1;
+    if (big) {
+        vs = c->view_slot;
+        c->view_slot = (vs + 1) % kifs_ctx::VIEW_RING;
+        if (!c->d_views[vs]) {
+            const size_t bytes = sizeof(kifs::BatchView) * size_t(kifs::MAX_BATCH);
+            if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_views[vs]), bytes), "hipMalloc(view table)") ||
+                !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_views[vs]), bytes, hipHostMallocDefault), "hipHostMalloc(view table)") ||
+                !hip_ok(hipEventCreateWithFlags(&c->views_used[vs], hipEventDisableTiming), "hipEventCreate(view table)"))
+                return KIFS_ERR_RUNTIME;
+        }
+        // the launch that last read this slot (four big launches ago) must be over before its images change
+        if (c->views_busy[vs] && !hip_ok(hipEventSynchronize(c->views_used[vs]), "wait(view table)")) return KIFS_ERR_RUNTIME;
+        c->views_busy[vs] = false;
+    }
     for (int i = 0; i < count; ++i) {
         const KifsCameraUniform& cam = cameras ? cameras[i] : c->camera;
-        kifs::BatchView& v = B.view[i];
+        kifs::BatchView& v = big ? c->h_views[vs][i] : B.view[i];
         v.origin = {cam.origin[0], cam.origin[1], cam.origin[2]};
         v.m0 = {cam.matrix[0][0], cam.matrix[0][1], cam.matrix[0][2]};
         v.m1 = {cam.matrix[1][0], cam.matrix[1][1], cam.matrix[1][2]};
@@ -475,10 +501,11 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
                 }
         }
     }
-    P.origin = B.view[0].origin;
-    P.m0 = B.view[0].m0;
-    P.m1 = B.view[0].m1;
-    P.m2 = B.view[0].m2;
+    const kifs::BatchView& view0 = big ? c->h_views[vs][0] : B.view[0];
+    P.origin = view0.origin;
+    P.m0 = view0.m0;
+    P.m1 = view0.m1;
+    P.m2 = view0.m2;
     const int h = P.y1;
     if (y0 < 0 || y1 > h || y0 > y1) return KIFS_ERR_BAD_ARG;
     if (pitch < size_t(P.width) * 4 || (pitch & 3u) != 0 || (pitch >> 2) > 0xffffffffull)
@@ -634,9 +661,19 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     }
     c->last_round_steps = P.round_steps;
     c->last_group_tiles = P.round_steps > 0 ? P.group_tiles : -1;
+    if (big) {
+        if (!hip_ok(hipMemcpyAsync(c->d_views[vs], c->h_views[vs], sizeof(kifs::BatchView) * size_t(count),
+                                   hipMemcpyHostToDevice, stream), "copy(view table)"))
+            return KIFS_ERR_RUNTIME;
+        B.table = c->d_views[vs];
+    }
     hipError_t e = kifs::launch_render(B, c->options.fractal_group_id, c->options.primitive_id,
                                        stream);
     if (!hip_ok(e, "render_kernel launch")) return KIFS_ERR_RUNTIME;
+    if (big) {
+        if (!hip_ok(hipEventRecord(c->views_used[vs], stream), "record(view table)")) return KIFS_ERR_RUNTIME;
+        c->views_busy[vs] = true;
+    }
     if (timed) {
         if (!hip_ok(hipEventRecord(c->prof_b[pslot], stream), "record(profile stop)")) return KIFS_ERR_RUNTIME;
         ++c->prof_count;
@@ -743,6 +780,14 @@ void kifs_destroy(kifs_ctx* c) {
     for (hipEvent_t ev : c->prof_a) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->prof_b) if (ev) (void)hipEventDestroy(ev);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    for (int i = 0; i < kifs_ctx::VIEW_RING; ++i) {
+        if (c->views_used[i]) {
+            (void)hipEventSynchronize(c->views_used[i]);
+            (void)hipEventDestroy(c->views_used[i]);
+        }
+        if (c->d_views[i]) (void)hipFree(c->d_views[i]);
+        if (c->h_views[i]) (void)hipHostFree(c->h_views[i]);
+    }
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_srgb) (void)hipFree(c->d_srgb);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);

@@ -39,12 +39,24 @@ constexpr int BLOCK = TILE_W * TILE_H;  // 256 threads = 4 waves
 __device__ __forceinline__ FrameParams batch_frame(const BatchParams& B, uint32_t view) {
     FrameParams P = B.frame;
     if (B.count > 1) {  // uniform; a batch of one carries its view in B.frame already
-        const BatchView& v = B.view[view];
-        P.origin = v.origin;
-        P.m0 = v.m0;
-        P.m1 = v.m1;
-        P.m2 = v.m2;
-        P.out = v.out;
+        if (B.table) {
+            // a table in device memory, read through the constant address space: the index is uniform, so
+            // these are scalar loads like the kernel argument's own (a generic pointer would cost VGPRs)
+            typedef const BatchView __attribute__((address_space(4))) * ConstView;
+            const ConstView v = (ConstView)(B.table + view);
+            P.origin = V3{v->origin.x, v->origin.y, v->origin.z};
+            P.m0 = V3{v->m0.x, v->m0.y, v->m0.z};
+            P.m1 = V3{v->m1.x, v->m1.y, v->m1.z};
+            P.m2 = V3{v->m2.x, v->m2.y, v->m2.z};
+            P.out = v->out;
+        } else {
+            const BatchView& v = B.view[view];
+            P.origin = v.origin;
+            P.m0 = v.m0;
+            P.m1 = v.m1;
+            P.m2 = v.m2;
+            P.out = v.out;
+        }
     }
     return P;
 }

@@ -81,9 +81,12 @@ struct FrameParams {
 
 // A launch renders a batch of up to MAX_BATCH frames that share screen, options and tile
 // order and differ in camera and destination (the frames of an orbit).  One frame's run time
-// is the critical path of a few long rays with most SIMDs idle; a batch fills them.  The views
-// travel in the kernel argument (56 B each: 2.1 KB with the frame constants, limit 4 KB).
-constexpr int MAX_BATCH = 64;
+// is the critical path of a few long rays with most SIMDs idle; a batch fills them.  Up to
+// MAX_BATCH_INLINE views travel in the kernel argument (56 B each: 3.9 KB with the frame constants,
+// limit 4 KB); a bigger batch -- the row shards of a multi-GPU step: a rank's eighth of 384 frames is
+// the work of 48 whole ones -- reads them from a device table the host uploads before the launch.
+constexpr int MAX_BATCH = 512;
+constexpr int MAX_BATCH_INLINE = 64;
 struct BatchView {
     V3 origin, m0, m1, m2;  // CameraUniform of this frame
     uint32_t* out;          // first row of its band
@@ -91,7 +94,8 @@ struct BatchView {
 struct BatchParams {
     FrameParams frame;      // everything common; its camera fields and `out` are those of view 0
     int count;              // 1..MAX_BATCH
-    BatchView view[MAX_BATCH];
+    const BatchView* table; // non-null: the views live there (count > MAX_BATCH_INLINE)
+    BatchView view[MAX_BATCH_INLINE];
 };
 
 }  // namespace kifs

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 
-MAX_BATCH = 64  # KIFS_MAX_BATCH of include/kifs_hip.h
+MAX_BATCH = 512  # KIFS_MAX_BATCH of include/kifs_hip.h
 SPARSE_RECORD_BYTES = 1040  # KIFS_SPARSE_RECORD_BYTES
 STRIPE_ROWS = 8  # KIFS_STRIPE_ROWS
 from ._lib import (CameraDataC, CameraUniform, ExtensionsC, GuiDataC, KifsError, OptionsUniform,
@@ -131,6 +131,31 @@ class GuiData:  # data.rs:131-160 (defaults = GuiData::default)
 def uniform_bytes(u) -> bytes:
     """`bytemuck::bytes_of` of a uniform struct."""
     return bytes(memoryview(u).cast("B"))
+
+
+class DevicePointers:
+    """The destinations of a batch, prepared once: a C array of device pointers (and the tensors, kept alive).
+    render_batch_async / render_shard_async take it in place of the list of tensors -- a step of a few hundred
+    views otherwise spends as long collecting pointers on the host as the GPU spends rendering."""
+
+    def __init__(self, outs):
+        self.tensors = list(outs)
+        self.array = (C.c_void_p * len(self.tensors))(*[_device_pointer(o) for o in self.tensors])
+
+    def __len__(self):
+        return len(self.tensors)
+
+    def __getitem__(self, i):
+        return self.tensors[i]
+
+
+def camera_array(cameras):
+    """A C array of CameraUniform images from CameraData objects / uniform images (prepared once per
+    sequence of poses; the render calls take it in place of the list)."""
+    if isinstance(cameras, C.Array):
+        return cameras
+    return (CameraUniform * len(cameras))(*[c.into_buffer_data() if hasattr(c, "into_buffer_data") else c
+                                            for c in cameras])
 
 
 def _device_pointer(obj):
@@ -304,9 +329,8 @@ class GraphicState:
             if not stream:
                 raise ValueError("render_batch_async: pass a non-default torch.cuda.Stream")
         n = len(outs)
-        cams = (CameraUniform * n)(*[c.into_buffer_data() if hasattr(c, "into_buffer_data") else c
-                                     for c in cameras])
-        ptrs = (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
+        cams = camera_array(cameras)
+        ptrs = outs.array if isinstance(outs, DevicePointers) else (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
         check(lib.kifs_render_batch_async(self._ctx, stream, n, cams, ptrs, pitch, y0, y1, encode),
               "render_batch_async")
 
@@ -324,9 +348,8 @@ class GraphicState:
             if not stream:
                 raise ValueError("render_shard_async: pass a non-default torch.cuda.Stream")
         n = len(outs)
-        cams = (CameraUniform * n)(*[c.into_buffer_data() if hasattr(c, "into_buffer_data") else c
-                                     for c in cameras])
-        ptrs = (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
+        cams = camera_array(cameras)
+        ptrs = outs.array if isinstance(outs, DevicePointers) else (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
         st = _stripe_array(stripes)
         check(lib.kifs_render_shard_async(self._ctx, stream, n, cams, ptrs, pitch, st, len(st),
                                           1 if in_place else 0, encode), "render_shard_async")

@@ -308,11 +308,11 @@ def test_batch_launch_argument_checks(gs, kifs):
     gs.update_screen_data(kifs.ScreenData(64, 40))
     gs.update_options(kifs.GuiData())
     out = torch.zeros((40, 64, 4), dtype=torch.uint8, device="cuda:0")
-    cams = (CameraUniform * 65)(*[kifs.CameraData().into_buffer_data() for _ in range(65)])
-    ptrs = (C.c_void_p * 65)(*[out.data_ptr()] * 65)
+    cams = (CameraUniform * 513)(*[kifs.CameraData().into_buffer_data() for _ in range(513)])
+    ptrs = (C.c_void_p * 513)(*[out.data_ptr()] * 513)
     call = lambda n, cams_, ptrs_, pitch=256, y0=0, y1=40, enc=1: lib.kifs_render_batch_async(
         gs._ctx, None, n, cams_, ptrs_, pitch, y0, y1, enc)
-    assert call(0, cams, ptrs) == 7 and call(65, cams, ptrs) == 7 and call(-1, cams, ptrs) == 7  # BAD_ARG
+    assert call(0, cams, ptrs) == 7 and call(513, cams, ptrs) == 7 and call(-1, cams, ptrs) == 7  # BAD_ARG
     assert call(2, None, ptrs) == 7 and call(2, cams, None) == 7
     null_second = (C.c_void_p * 2)(out.data_ptr(), None)
     assert call(2, cams, null_second) == 7

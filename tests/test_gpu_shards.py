@@ -100,9 +100,9 @@ def test_headline_shards_take_the_requeuing_kernel(gs, kifs, oracle):
 
 
 def test_batch_of_64_frames(gs, kifs, oracle):
-    """KIFS_MAX_BATCH = 64 views in one launch (kernel argument of 3.9 KB, limit 4 KB)."""
+    """64 views in one launch: the most that travel in the kernel argument (3.9 KB, limit 4 KB)."""
     import torch
-    assert kifs.MAX_BATCH == 64
+    assert kifs.MAX_BATCH == 512
     gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=64)
     screen = kifs.ScreenData(128, 72)
     gs.update_screen_data(screen)
@@ -118,7 +118,43 @@ def test_batch_of_64_frames(gs, kifs, oracle):
         assert (got[k] == oracle_frame(oracle, kifs, screen, cams[k], gui, (12, 10, 10))).all(), k
     assert len({got[k].tobytes() for k in range(64)}) == 64
     with pytest.raises(ValueError):
-        gs.render_batch_async([outs[0]] * 65, cams + cams[:1], stream=stream)
+        gs.render_batch_async([outs[0]] * 513, (cams * 9)[:513], stream=stream)
+
+
+def test_batches_beyond_the_kernel_argument(gs, kifs, oracle):
+    """65 .. KIFS_MAX_BATCH = 512 views: the views go through a device table (a ring of four, uploaded before
+    the launch).  A 384-frame shard launch -- what a rank of eight renders per step -- and six launches in a
+    row on two streams with different cameras (the ring wraps); every checked frame == the oracle."""
+    import torch
+    gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=64)
+    W, H = 256, 144
+    screen = kifs.ScreenData(W, H)
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(12, 10, 10)
+    cam = lambda k: kifs.CameraData(origin_distance=3.0 + 0.002 * k, phi=0.05 * k, theta=0.001 * k - 0.4)
+    stripes, rows = kifs.shard_stripes(H, 3, 8)
+    n = 384
+    shards = torch.zeros((n, rows, W, 4), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    gs.render_shard_async([shards[i] for i in range(n)], [cam(k) for k in range(n)], stripes, stream=stream)
+    stream.synchronize()
+    got = shards.cpu().numpy()
+    ys = [y for s in stripes for y in range(8 * s, min(H, 8 * s + 8))]
+    for k in (0, 63, 64, 65, 200, 383):
+        assert (got[k] == oracle_frame(oracle, kifs, screen, cam(k), gui, (12, 10, 10))[ys]).all(), k
+    # the ring: six whole-frame launches of 80..85 views back to back, alternating streams
+    other = torch.cuda.Stream()
+    outs = [torch.zeros((80 + j, H, W, 4), dtype=torch.uint8, device="cuda:0") for j in range(6)]
+    for j in range(6):
+        gs.render_batch_async([outs[j][i] for i in range(80 + j)], [cam(1000 * j + i) for i in range(80 + j)],
+                              stream=(stream, other)[j % 2])
+    stream.synchronize()
+    other.synchronize()
+    for j in range(6):
+        for i in (0, 64, 79 + j):
+            want = oracle_frame(oracle, kifs, screen, cam(1000 * j + i), gui, (12, 10, 10))
+            assert (outs[j][i].cpu().numpy() == want).all(), (j, i)
 
 
 def test_shard_argument_checks(gs, kifs):
@@ -143,7 +179,7 @@ def test_shard_argument_checks(gs, kifs):
     assert lib.kifs_render_shard_async(gs._ctx, None, 2, cams, ptrs, 256, None, 1, 1, 1) == 7  # NULL list
     assert call(arr(0), cams_=None) == 7          # no cameras for two frames
     assert call(arr(0), count=1, cams_=None) == 0  # one frame: the context's camera
-    assert call(arr(0), count=65) == 7
+    assert call(arr(0), count=513) == 7
     assert call(arr(0), pitch=100) == 3
     assert call(arr(0), enc=9) == 7
     un = lambda st, fp=256, sp=256: lib.kifs_unpack_shard_async(gs._ctx, None, 2, out.data_ptr(), fp, 40 * 256,
