@@ -444,7 +444,13 @@ def main():
     count_group = fill_stream = None
     if sharded and args.gather == "sparse":
         # message sizes travel between the hosts over a CPU group, beside the RCCL transfers
-        count_group = dist.new_group(backend="gloo") if args.backend == "nccl" else None
+        if args.backend == "nccl":
+            try:
+                count_group = dist.new_group(backend="gloo")
+            except Exception as e:  # every rank sees the same environment: all fall back together
+                print(f"bench.py: no CPU group for the message sizes ({e}); they will travel through device memory",
+                      file=sys.stderr)
+                count_group = None
         fill_stream = torch.cuda.Stream(device=device)
     root_weight, calibration = 1, None
     if sharded:
