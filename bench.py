@@ -75,11 +75,11 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1, row shards: frames per step = N x frames-per-launch (weak) or frames-per-launch")
     ap.add_argument("--root-weight", default="auto",
-                    help="N > 1, stripes: rank 0 renders this many stripes for every one of a peer.  Every peer's "
-                         "pixels reach rank 0 over ONE point-to-point xGMI link, far slower than a GPU renders "
-                         "them; 'auto' (default) times one step's rendering and one step's gather with equal "
-                         "shares during warm-up and gives rank 0 the share at which its rendering takes as long "
-                         "as the peers' transfers; an integer fixes the weight (1 = equal shares)")
+                    help="N > 1, stripes: W or W:P -- rank 0 renders W stripes for every P (default 1) of a peer.  "
+                         "Rank 0 also takes every peer's pixels in (each over ONE point-to-point xGMI link) and writes "
+                         "the background under their rows: 'auto' (default) times, with equal shares during warm-up, "
+                         "one step's rendering on rank 0, one step's gather, and the peers' side of it, and picks the "
+                         "shares at which rank 0 and the peers take equally long")
     ap.add_argument("--deliver", default="none", choices=["none", "root"],
                     help="N > 1, --shard frames: leave frames where they were rendered, or send them to rank 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -348,12 +348,12 @@ def main():
                 fs.step(k, render)
         return fs, step
 
-    def row_shards(frames_per_step, camera_mode, contiguous, root_weight=1):
+    def row_shards(frames_per_step, camera_mode, contiguous, root_weight=(1, 1)):
         """The north star's path: every rank renders its row shard of the step's frames (launches of
         at most MAX_BATCH frames) and rank 0 gathers them."""
         weights = None
-        if not contiguous and root_weight != 1:
-            weights = [root_weight] + [1] * (world - 1)
+        if not contiguous and root_weight[0] != root_weight[1]:
+            weights = [root_weight[0]] + [root_weight[1]] * (world - 1)
         if args.gather == "sparse":
             slots = {}  # per payload buffer: the record count on the device, in pinned host memory, and its event
 
@@ -402,12 +402,16 @@ def main():
         return sf, step
 
     def calibrate_root_weight(frames_per_step):
-        """Equal shares first: time rank 0's rendering of one step and, separately, one step's gather
-        (all peers sending at once, each over its own link, plus the unpack).  With rank 0 at weight w
-        its rendering scales by w N / (w + N - 1) and every transfer by N / (w + N - 1): they take
-        equally long at w = t_gather / t_render.  Rank 0 decides, everybody follows."""
+        """Equal shares first: time rank 0's rendering of one step, one step's gather (all peers sending at once,
+        each over its own link; rank 0's fill / unpack) and what a peer spends on its side before its message is
+        out (the pack).  A rank at weight w of the total T renders s = N w / T of an equal share.  Model:
+            rank 0:  t_render s0 + t_gather (N - s0) / (N - 1)      (it fills / unpacks what it does not render)
+            a peer:  (t_render + t_pack) s1
+        and the shares (root : peer, small integers) with the smallest maximum win.  With every row crossing the
+        links (--gather dense) the gather dominates and rank 0 gets several times a peer's share; with sparse
+        shards it is rank 0's own fill that counts and the peers get more.  Rank 0 decides, everybody follows."""
         sf, step = row_shards(frames_per_step, args.camera, contiguous=False)
-        t_render = t_gather = 0.0
+        t_render = t_gather = t_pack = 0.0
         with torch.cuda.stream(streams[0]):
             for k in range(2):
                 step(k)
@@ -423,7 +427,8 @@ def main():
                 t1 = time.perf_counter()
                 barrier()
                 t2 = time.perf_counter()
-                sf.gather_async(k)
+                sf.gather_async(k)   # sparse: returns once this rank's record count is on its host (the pack is done)
+                t2b = time.perf_counter()
                 sf.wait(k)
                 torch.cuda.synchronize()
                 barrier()
@@ -431,13 +436,28 @@ def main():
                 if k > 2:  # the first timed pass still warms things up
                     t_render += (t1 - t0) / 2
                     t_gather += (t3 - t2) / 2
-        w = max(1, min(16, int(round(t_gather / max(t_render, 1e-9))))) if rank == 0 else 0
-        t = torch.tensor([w], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
+                    t_pack += (t2b - t2) / 2 if rank != 0 else 0.0
+        on = device if args.backend == "nccl" else "cpu"
+        tp = torch.tensor([t_pack], dtype=torch.float64, device=on)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        t_pack = float(tp.item())
+        best = (1, 1)
+        if rank == 0:
+            candidates = [(k, 1) for k in range(1, 17)] + [(1, 2), (1, 3), (1, 4), (2, 3), (3, 4), (3, 2), (5, 2)]
+            cost = {}
+            for w0, w1 in candidates:
+                total = w0 + (world - 1) * w1
+                s0, s1 = world * w0 / total, world * w1 / total
+                cost[(w0, w1)] = max(t_render * s0 + t_gather * (world - s0) / (world - 1), (t_render + t_pack) * s1)
+            floor = min(cost.values())  # among the shares within 3 % of the best, the most even ones
+            best = min((c for c in candidates if cost[c] <= 1.03 * floor), key=lambda c: (max(c) / min(c), cost[c]))
+        t = torch.tensor(list(best), dtype=torch.int64, device=on)
         dist.broadcast(t, src=0)
         del sf
         torch.cuda.empty_cache()  # the calibration's frame buffers must not sit beside the run's
-        return int(t.item()), {"render_ms_equal_shares": round(t_render * 1e3, 4),
-                               "gather_ms_equal_shares": round(t_gather * 1e3, 4)}
+        return (int(t[0].item()), int(t[1].item())), {"render_ms_equal_shares": round(t_render * 1e3, 4),
+                                                      "gather_ms_equal_shares": round(t_gather * 1e3, 4),
+                                                      "peer_pack_ms_equal_shares": round(t_pack * 1e3, 4)}
 
     # ---- the headline sequence
     sharded = world > 1 and args.shard in ("stripes", "bands")
@@ -452,7 +472,7 @@ def main():
                       file=sys.stderr)
                 count_group = None
         fill_stream = torch.cuda.Stream(device=device)
-    root_weight, calibration = 1, None
+    root_weight, calibration = (1, 1), None
     if sharded:
         frames_per_step = B * world if args.scaling == "weak" else B
         # rank 0 keeps two buffers of the step's finished frames: at most 24 GB of them (8K frames: 90)
@@ -461,7 +481,8 @@ def main():
             if args.root_weight == "auto":
                 root_weight, calibration = calibrate_root_weight(frames_per_step)
             else:
-                root_weight = max(1, int(args.root_weight))
+                parts = [max(1, int(x)) for x in str(args.root_weight).split(":")]
+                root_weight = (parts[0], parts[1] if len(parts) > 1 else 1)
         pipe, step = row_shards(frames_per_step, args.camera, contiguous=(args.shard == "bands"),
                                 root_weight=root_weight)
         rows0 = pipe.rows[rank]
@@ -571,7 +592,7 @@ def main():
             parallelism = (f"{world} GPUs, one process each: row shards ("
                            + ("contiguous bands of 8-row stripes" if args.shard == "bands" else
                               "8-row stripes dealt round-robin"
-                              + (f", rank 0 weighted x{root_weight}" if root_weight != 1 else ""))
+                              + (f", rank 0 : peer = {root_weight[0]} : {root_weight[1]}" if root_weight[0] != root_weight[1] else ""))
                            + f") of {frames_per_step} frames per step, gathered into rank 0's frames by grouped "
                            "RCCL point-to-point over xGMI"
                            + (": peers send the 32x8 tiles that hold something, rank 0 fills in the background"
@@ -612,7 +633,8 @@ def main():
             "per_rank_step_ms": [round(x, 5) for x in per_rank_step_ms],
         }
         if sharded:
-            out["config"]["root_weight"] = root_weight
+            out["config"]["root_weight"] = root_weight[0]
+            out["config"]["peer_weight"] = root_weight[1]
             out["config"]["rows_per_rank"] = pipe.rows
             out["config"]["gather"] = args.gather
             if args.gather == "sparse" and pipe.tiles_seen:

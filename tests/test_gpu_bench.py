@@ -60,7 +60,9 @@ def test_two_ranks_are_started_by_bench_itself_and_gather_exact_frames():
     assert d["gathered_frame_equals_single_gpu_frame"] is True
     cfg = d["config"]
     assert cfg["frames_per_step"] == 8 and "8-row stripes" in cfg["parallelism"] and "RCCL" in cfg["parallelism"]
-    assert cfg["root_weight"] >= 1 and sum(cfg["rows_per_rank"]) == 1080
-    assert set(cfg["root_weight_calibration"]) == {"render_ms_equal_shares", "gather_ms_equal_shares"}
+    assert cfg["root_weight"] >= 1 and cfg["peer_weight"] >= 1 and sum(cfg["rows_per_rank"]) == 1080
+    assert set(cfg["root_weight_calibration"]) == {"render_ms_equal_shares", "gather_ms_equal_shares",
+                                                   "peer_pack_ms_equal_shares"}
+    assert cfg["gather"] == "sparse" and 0.0 < cfg["tiles_sent_fraction"] < 0.2
     assert len(d["per_rank_kernel_ms"]) == 2 and all(x > 0 for x in d["per_rank_kernel_ms"])
     assert "frame_parallel" in d["secondary"] and "NOT the north star" in d["secondary"]["frame_parallel"]["note"]

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Rank 0's side of a step of the default 8-GPU run, on ONE GPU: its own shard of 384 frames (one launch),
+the background under the seven peers' rows (kifs_fill_shard_async on a second stream) and the scatter of
+their records -- alone and together.   python tools/root_side_study.py [world]"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+import kifs_raymarching_amd as K  # noqa: E402
+from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera  # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+w = WORKLOADS["cfg2_julia_1080p"]
+W, H = w.screen.width, w.screen.height
+gs = K.GraphicState(0, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
+gs.set_iters(*w.iters)
+F = 48 * world
+frames = torch.zeros((F, H, W, 4), dtype=torch.uint8, device="cuda:0")
+cams = K.camera_array([orbit_camera(w, k) for k in range(F)])
+mine, _ = K.shard_stripes(H, 0, world)
+peers = sorted(s for r in range(1, world) for s in K.shard_stripes(H, r, world)[0])
+outs = K.DevicePointers([frames[i] for i in range(F)])
+a, b = torch.cuda.Stream(), torch.cuda.Stream()
+# a peer's records: render its shard, pack it
+st1, rows1 = K.shard_stripes(H, 1, world)
+shard = torch.zeros((F, rows1, W, 4), dtype=torch.uint8, device="cuda:0")
+gs.render_shard_async([shard[i] for i in range(F)], cams, st1, stream=a)
+records = torch.zeros((gs.sparse_capacity(F, st1), 1040), dtype=torch.uint8, device="cuda:0")
+n_dev = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+n_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+gs.pack_sparse_async(shard, st1, records, n_dev, n_host, stream=a)
+a.synchronize()
+n = int(n_host[0])
+print(f"world {world}: {F} frames per step; a peer's shard: {n} records of {records.shape[0]} tiles "
+      f"({100.0 * n / records.shape[0]:.1f} %), {n * 1040 / 1e6:.1f} MB instead of {shard.numel() / 1e6:.0f} MB")
+
+
+def timed(label, body, reps=10):
+    for _ in range(3):
+        body()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        body()
+        b.wait_stream(a)
+        torch.cuda.current_stream().wait_stream(b)
+        a.wait_stream(torch.cuda.current_stream())
+    t1.record()
+    torch.cuda.synchronize()
+    print(f"  {label:58s}: {t0.elapsed_time(t1) / reps:.3f} ms per step")
+
+
+render = lambda: gs.render_shard_async(outs, cams, mine, in_place=True, stream=a)
+fill = lambda s: gs.fill_shard_async(frames, peers, stream=s)
+unpack = lambda s: [gs.unpack_sparse_async(frames, records, n, st1, stream=s) for _ in range(world - 1)]
+pack = lambda: gs.pack_sparse_async(shard, st1, records, n_dev, n_host, stream=a)
+timed("its own shard (one launch)", render)
+timed("background under the peers' rows", lambda: fill(a))
+timed("scatter of the peers' records", lambda: unpack(a))
+timed("a peer's pack of its shard", pack)
+timed("shard on one stream, fill + scatter on another", lambda: (render(), fill(b), unpack(b)))
+timed("all on one stream", lambda: (render(), fill(a), unpack(a)))
