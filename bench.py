@@ -376,7 +376,9 @@ def main():
                 unpack_sparse=lambda frames, records, n, stripes: gs.unpack_sparse_async(
                     frames, records, n, stripes, stream=streams[0]),
                 fill=lambda frames, stripes: gs.fill_shard_async(
-                    frames, stripes, stream=torch.cuda.current_stream(), encode=args.encode))
+                    frames, stripes, stream=torch.cuda.current_stream(), encode=args.encode),
+                erase=lambda frames, records, n, stripes: gs.erase_sparse_async(
+                    frames, records, n, stripes, stream=torch.cuda.current_stream(), encode=args.encode))
         else:
             sf = ShardFrames(W, H, rank, world, device, frames_per_step=frames_per_step, buffers=2,
                              weights=weights, contiguous=contiguous,

@@ -240,7 +240,10 @@ int kifs_unpack_shard_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t*
  * kifs_unpack_sparse_async: the root's side.  Writes records [0, n_records) to their rows of the
  *   frames dev_frames + i * frame_stride; records whose id is out of range are skipped.
  * kifs_fill_shard_async: the background over the rows of the listed stripes of `count` frames
- *   (what the records leave out; any order with kifs_unpack_sparse_async's stream, before it). */
+ *   (what the records leave out; any order with kifs_unpack_sparse_async's stream, before it).
+ * kifs_erase_sparse_async: the background over the tiles of records [0, n_records) only -- frame
+ *   buffers that are reused need it back just where the previous frames' records went (2 % of the
+ *   headline's tiles) instead of a fill of every row. */
 #define KIFS_SPARSE_RECORD_BYTES 1040
 int kifs_pack_sparse_async(kifs_ctx* ctx, void* hip_stream, int count, const uint8_t* dev_shards,
                            size_t shard_pitch, size_t shard_stride, const int* stripes, int n_stripes,
@@ -252,6 +255,9 @@ int kifs_unpack_sparse_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t
 int kifs_fill_shard_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t* dev_frames,
                           size_t frame_pitch, size_t frame_stride, const int* stripes, int n_stripes,
                           int encode);
+int kifs_erase_sparse_async(kifs_ctx* ctx, void* hip_stream, int count, uint8_t* dev_frames,
+                            size_t frame_pitch, size_t frame_stride, const uint8_t* dev_records,
+                            size_t n_records, const int* stripes, int n_stripes, int encode);
 
 /* ---- single-process multi-GPU ------------------------------------------------------
  * For a host that drives all GPUs of a node from one process (the reference's host is one

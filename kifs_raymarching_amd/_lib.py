@@ -90,6 +90,8 @@ SIGNATURES = {
                                            C.c_size_t, _P(C.c_int), C.c_int]),
     "kifs_fill_shard_async": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, _P(C.c_int),
                                         C.c_int, C.c_int]),
+    "kifs_erase_sparse_async": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                          C.c_size_t, _P(C.c_int), C.c_int, C.c_int]),
     "kifs_multi_create": (_ctx, [_P(C.c_int), C.c_int, _P(C.c_int)]),
     "kifs_multi_destroy": (None, [_ctx]),
     "kifs_multi_set_screen": (C.c_int, [_ctx, _P(ScreenUniform)]),

@@ -403,6 +403,13 @@ def unpack_sparse_torch(frames: torch.Tensor, records: torch.Tensor, stripes) ->
         frames[shard, y0:y0 + h, x0:x0 + w] = rec[16:].view(STRIPE_ROWS, _TILE_W, 4)[:h, :w]
 
 
+def erase_sparse_torch(frames: torch.Tensor, records: torch.Tensor, stripes, background_rgba: int) -> None:
+    """CPU form of kifs_erase_sparse_async: the background over the records' tiles."""
+    blank = records.clone()
+    blank[:, 16:] = torch.tensor([(background_rgba >> s) & 255 for s in (0, 8, 16, 24)], dtype=torch.uint8).repeat(STRIPE_ROWS * _TILE_W)
+    unpack_sparse_torch(frames, blank, stripes)
+
+
 def fill_stripes_torch(frames: torch.Tensor, stripes, background_rgba: int) -> None:
     bg = torch.tensor([(background_rgba >> s) & 255 for s in (0, 8, 16, 24)], dtype=torch.uint8, device=frames.device)
     for s in stripes:
@@ -426,20 +433,25 @@ class SparseShardFrames(ShardFrames):
     rendering; then the payload of step k is posted.  So transfers lag the rendering by one step, exactly as
     the dense form's do, and nothing on the GPU waits for the host.
 
+    A frame buffer that comes round again still holds the background everywhere but under its previous
+    records: with `erase` given, only those tiles are reset (2 % of the headline's) instead of every row.
+
     pack(shards, stripes, records) -> callable returning the number of records (may block until known);
-    unpack_sparse(frames, records, n, stripes); fill(frames, stripes): device forms from GraphicState
+    unpack_sparse(frames, records, n, stripes); fill(frames, stripes); erase(frames, records, n, stripes)
+    (optional): device forms from GraphicState
     (bench.py) or the *_torch functions above bound to a background pixel (CPU tests)."""
 
     def __init__(self, width: int, height: int, rank: int, world: int, device, frames_per_step: int = 1,
                  root: int = 0, buffers: int = 2, group=None, weights=None, contiguous: bool = False,
-                 pack: Callable = None, unpack_sparse: Callable = None, fill: Callable = None, count_group=None,
-                 fill_stream=None):
+                 pack: Callable = None, unpack_sparse: Callable = None, fill: Callable = None, erase: Callable = None,
+                 count_group=None, fill_stream=None):
         if pack is None or unpack_sparse is None or fill is None:
             raise ValueError("SparseShardFrames: pack, unpack_sparse and fill are required")
         if buffers < 2:
             raise ValueError("SparseShardFrames: transfers lag the rendering by a step: at least two buffers")
         super().__init__(width, height, rank, world, device, frames_per_step, root, buffers, group, weights, contiguous)
-        self.pack, self.unpack_sparse, self.fill = pack, unpack_sparse, fill
+        self.pack, self.unpack_sparse, self.fill, self.erase = pack, unpack_sparse, fill, erase
+        self._filled = [False] * buffers      # root: the slot's frames hold the background outside its last records
         self.count_group = count_group if count_group is not None else group
         self.fill_stream = fill_stream
         self._count_fn = [None] * buffers     # peer: the step's record count, once the host may know it
@@ -474,13 +486,22 @@ class SparseShardFrames(ShardFrames):
         slot = k % self.buffers
         if self.rank != self.root or self.world == 1 or not self.peer_stripes:
             return
+        def background():
+            if self.erase is not None and self._filled[slot]:  # only where the slot's previous records went
+                counts = self._counts[slot]
+                for r in range(self.world):
+                    if r != self.root and counts[r] > 0:
+                        self.erase(self._frames[slot], self._recv[slot][r], counts[r], self.stripes[r])
+            else:
+                self.fill(self._frames[slot], self.peer_stripes)
+                self._filled[slot] = True
         if self.fill_stream is not None:
             self.fill_stream.wait_event(self._slot_free[slot] or torch.cuda.current_stream().record_event())
             with torch.cuda.stream(self.fill_stream):
-                self.fill(self._frames[slot], self.peer_stripes)
+                background()
                 self._fill_done[slot] = self.fill_stream.record_event()
         else:
-            self.fill(self._frames[slot], self.peer_stripes)
+            background()
 
     def _pack(self, k: int):
         """Peer, after step k's rendering is enqueued."""
@@ -510,6 +531,9 @@ class SparseShardFrames(ShardFrames):
         self._counts[slot] = counts
         ops = []
         if self.rank == self.root:
+            if self._fill_done[slot] is not None:
+                # the erase reads the slot's previous records: it precedes the receives that overwrite them
+                torch.cuda.current_stream().wait_event(self._fill_done[slot])
             for r in range(self.world):
                 if r != self.root and counts[r] > 0:
                     if counts[r] > self.capacity[r]:

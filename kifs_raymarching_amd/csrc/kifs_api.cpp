@@ -970,17 +970,18 @@ int kifs_pack_sparse_async(kifs_ctx* c, void* hip_stream, int count, const uint8
     return KIFS_OK;
 }
 
-int kifs_unpack_sparse_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch,
-                             size_t frame_stride, const uint8_t* dev_records, size_t n_records, const int* stripes,
-                             int n_stripes) {
+namespace {
+int unpack_or_erase(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch, size_t frame_stride,
+                    const uint8_t* dev_records, size_t n_records, const int* stripes, int n_stripes, bool erase, int encode) {
     if (!c || !dev_frames || !stripes || n_stripes < 0 || count < 0 || (n_records && !dev_records)) return KIFS_ERR_BAD_ARG;
     DeviceGuard g(c->device);
     if (!g.ok) return KIFS_ERR_RUNTIME;
-    if (!c->have_screen) return KIFS_ERR_UNCONFIGURED;
+    if (!c->have_screen || (erase && !c->have_options)) return KIFS_ERR_UNCONFIGURED;
     if (n_stripes == 0 || count == 0 || n_records == 0) return KIFS_OK;
     int w = 0, h = 0;
     const RowTable* rows = nullptr;
-    int st = sparse_setup(c, stripes, n_stripes, 0, &w, &h, &rows, nullptr);
+    uint32_t background = 0;
+    int st = sparse_setup(c, stripes, n_stripes, encode, &w, &h, &rows, erase ? &background : nullptr);
     if (st != KIFS_OK) return st;
     const size_t tiles = size_t(count) * size_t(n_stripes) * size_t((w + kifs::TILE_W - 1) / kifs::TILE_W);
     if (frame_pitch < size_t(w) * 4 || ((frame_pitch | frame_stride) & 3u) || n_records > tiles ||
@@ -988,8 +989,24 @@ int kifs_unpack_sparse_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* 
         return KIFS_ERR_BAD_SIZE;
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     return hip_ok(kifs::launch_unpack_sparse(dev_frames, frame_pitch, frame_stride, reinterpret_cast<const uint32_t*>(dev_records),
-                                             uint32_t(n_records), rows->d_rows, n_stripes, count, w, h, s),
+                                             uint32_t(n_records), rows->d_rows, n_stripes, count, w, h, erase ? 1 : 0,
+                                             background, s),
                   "unpack_sparse_kernel launch") ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+}  // namespace
+
+int kifs_unpack_sparse_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch,
+                             size_t frame_stride, const uint8_t* dev_records, size_t n_records, const int* stripes,
+                             int n_stripes) {
+    return unpack_or_erase(c, hip_stream, count, dev_frames, frame_pitch, frame_stride, dev_records, n_records, stripes,
+                           n_stripes, false, 0);
+}
+
+int kifs_erase_sparse_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch,
+                            size_t frame_stride, const uint8_t* dev_records, size_t n_records, const int* stripes,
+                            int n_stripes, int encode) {
+    return unpack_or_erase(c, hip_stream, count, dev_frames, frame_pitch, frame_stride, dev_records, n_records, stripes,
+                           n_stripes, true, encode);
 }
 
 int kifs_fill_shard_async(kifs_ctx* c, void* hip_stream, int count, uint8_t* dev_frames, size_t frame_pitch,

@@ -27,7 +27,7 @@ hipError_t launch_pack_sparse(const uint8_t* src, size_t src_pitch, size_t src_s
                               uint32_t* n_records, hipStream_t stream);
 hipError_t launch_unpack_sparse(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint32_t* records,
                                 uint32_t n_records, const uint32_t* stripe_rows, int n_stripes, int count, int width,
-                                int height, hipStream_t stream);
+                                int height, int erase, uint32_t background, hipStream_t stream);
 hipError_t launch_fill_stripes(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint32_t* stripe_rows,
                                int n_stripes, int count, int width, int height, uint32_t background, hipStream_t stream);
 hipError_t launch_eval_points(const FrameParams& P, uint32_t group, uint32_t primitive,

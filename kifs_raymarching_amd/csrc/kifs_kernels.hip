@@ -945,9 +945,12 @@ __global__ __launch_bounds__(256) void pack_sparse_kernel(
 
 // unpack: one wave per record; the tile goes to its frame rows, clipped to the frame.  Ids that do not
 // belong to the shard are skipped (the payload crossed a network).
+//   erase != 0: the record's tile is overwritten with `background` instead (a frame buffer that is reused
+//   needs the background back only where the previous frame's records went, not everywhere).
 __global__ __launch_bounds__(256) void unpack_sparse_kernel(
     uint8_t* __restrict__ dst, size_t dst_pitch, size_t dst_frame_stride, const uint32_t* __restrict__ records,
-    uint32_t n_records, const uint32_t* __restrict__ stripe_rows, int n_stripes, int count, int width, int height) {
+    uint32_t n_records, const uint32_t* __restrict__ stripe_rows, int n_stripes, int count, int width, int height,
+    int erase, uint32_t background) {
     const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (r >= n_records) return;
     const uint32_t* rec = records + size_t(r) * SPARSE_RECORD_WORDS;
@@ -958,7 +961,8 @@ __global__ __launch_bounds__(256) void unpack_sparse_kernel(
     const int row = int(lane >> 3), col = int(lane & 7u) * 4;
     const int y = int(stripe_rows[sk]) + row, x = int(tx) * TILE_W + col;
     if (y >= height || row >= TILE_H) return;
-    const uint4 v = *reinterpret_cast<const uint4*>(rec + 4 + row * TILE_W + col);
+    const uint4 v = erase ? make_uint4(background, background, background, background)
+                          : *reinterpret_cast<const uint4*>(rec + 4 + row * TILE_W + col);
     uint32_t* to = reinterpret_cast<uint32_t*>(dst + size_t(shard) * dst_frame_stride + size_t(y) * dst_pitch) + x;
     const uint32_t q[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1001,10 +1005,10 @@ hipError_t launch_pack_sparse(const uint8_t* src, size_t src_pitch, size_t src_s
 
 hipError_t launch_unpack_sparse(uint8_t* dst, size_t dst_pitch, size_t dst_frame_stride, const uint32_t* records,
                                 uint32_t n_records, const uint32_t* stripe_rows, int n_stripes, int count, int width,
-                                int height, hipStream_t stream) {
+                                int height, int erase, uint32_t background, hipStream_t stream) {
     if (n_records == 0 || n_stripes <= 0 || count <= 0) return hipSuccess;
     hipLaunchKernelGGL(unpack_sparse_kernel, dim3((n_records + 3u) / 4u), dim3(256), 0, stream, dst, dst_pitch,
-                       dst_frame_stride, records, n_records, stripe_rows, n_stripes, count, width, height);
+                       dst_frame_stride, records, n_records, stripe_rows, n_stripes, count, width, height, erase, background);
     return hipGetLastError();
 }
 

@@ -417,7 +417,11 @@ class GraphicState:
                                          _device_pointer(host_n_records) if host_n_records is not None else None),
               "pack_sparse_async")
 
-    def unpack_sparse_async(self, frames, records, n_records: int, stripes, stream=None):
+    def erase_sparse_async(self, frames, records, n_records: int, stripes, stream=None, encode: int = ENCODE_SRGB):
+        """The background over the tiles of the first `n_records` records (kifs_erase_sparse_async)."""
+        self.unpack_sparse_async(frames, records, n_records, stripes, stream=stream, _erase_encode=encode)
+
+    def unpack_sparse_async(self, frames, records, n_records: int, stripes, stream=None, _erase_encode=None):
         """Root side: the first `n_records` records of `records` -> their rows of `frames` (count, H, W, 4)."""
         w, h = self.screen_data.width, self.screen_data.height
         if frames.dim() != 4 or tuple(frames.shape[1:]) != (h, w, 4) or not frames.is_contiguous() or frames.element_size() != 1:
@@ -428,6 +432,12 @@ class GraphicState:
                 or not records.is_contiguous() or records.element_size() != 1)):
             raise ValueError("unpack_sparse_async: n_records records of 1040 bytes, at most one per tile of the shards")
         st = _stripe_array(stripes)
+        if _erase_encode is not None:
+            check(lib.kifs_erase_sparse_async(self._ctx, self._stream_handle(stream, "erase_sparse_async"), count,
+                                              _device_pointer(frames), w * 4, h * w * 4,
+                                              _device_pointer(records) if n_records else None, n_records, st, len(st),
+                                              _erase_encode), "erase_sparse_async")
+            return
         check(lib.kifs_unpack_sparse_async(self._ctx, self._stream_handle(stream, "unpack_sparse_async"), count,
                                            _device_pointer(frames), w * 4, h * w * 4,
                                            _device_pointer(records) if n_records else None, n_records, st, len(st)),

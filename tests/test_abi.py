@@ -88,6 +88,7 @@ def test_null_and_bad_arguments_do_not_crash(kifs):
     assert lib.kifs_pack_sparse_async(None, None, 1, None, 0, 0, None, 0, 1, None, 0, None, None) == 7
     assert lib.kifs_unpack_sparse_async(None, None, 1, None, 0, 0, None, 0, None, 0) == 7
     assert lib.kifs_fill_shard_async(None, None, 1, None, 0, 0, None, 0, 1) == 7
+    assert lib.kifs_erase_sparse_async(None, None, 1, None, 0, 0, None, 0, None, 0, 1) == 7
     n = C.c_int()
     assert lib.kifs_shard_stripes(8, 2, None, 0, None, 0, None, None) == 7          # nowhere to report the count
     assert lib.kifs_shard_stripes(64, 2, None, 0, None, 0, C.byref(n), None) == 0 and n.value == 4  # counting only

@@ -225,7 +225,9 @@ def _shard_worker(rank, world, port, width, height, steps, count, weights, conti
             sf = SparseShardFrames(width, height, rank, world, "cpu", frames_per_step=count, weights=weights,
                                    contiguous=contiguous, pack=pack,
                                    unpack_sparse=lambda frames, records, n, stripes: bands.unpack_sparse_torch(frames, records[:n], stripes),
-                                   fill=lambda frames, stripes: bands.fill_stripes_torch(frames, stripes, bg))
+                                   fill=lambda frames, stripes: bands.fill_stripes_torch(frames, stripes, bg),
+                                   erase=(lambda frames, records, n, stripes: bands.erase_sparse_torch(frames, records[:n], stripes, bg))
+                                   if world == 3 else None)
         else:
             sf = ShardFrames(width, height, rank, world, "cpu", frames_per_step=count, weights=weights,
                              contiguous=contiguous)
@@ -277,7 +279,7 @@ def test_shard_gather_equals_single_frames(world, height, count, weights, contig
     """bench.py's default at N > 1: every rank renders its stripes of the step's frames, one message
     per peer (dense rows, or records of the non-background tiles with the sizes exchanged a step behind),
     the root unpacks; the gathered frames equal single-process frames."""
-    steps = 4 if sparse else 3
+    steps = 5 if sparse else 3  # (sparse: every buffer slot comes round again, its previous records erased)
     mp.spawn(_shard_worker,
              args=(world, _free_port(), width, height, steps, count, weights, contiguous, str(tmp_path), sparse),
              nprocs=world, join=True)

@@ -431,6 +431,11 @@ def test_sparse_shards_on_the_gpu(size, gs, kifs, oracle):
     assert (frames[:, ys] == shards).all()
     others = [y for y in range(H) if y not in set(ys)]
     assert int(frames[:, others].max()) == 0, "rows of other ranks' stripes are not touched"
+    # a buffer that comes round again: the background back under these records only
+    gs.erase_sparse_async(frames, records, n, stripes, stream=stream)
+    stream.synchronize()
+    bgt = torch.tensor([(bg >> s) & 255 for s in (0, 8, 16, 24)], dtype=torch.uint8, device="cuda:0")
+    assert (frames[:, ys] == bgt).all() and int(frames[:, others].max()) == 0
     # a shard with no background: one record per tile; an all-background one: none
     noise = torch.randint(0, 200, shards.shape, dtype=torch.uint8, device="cuda:0")
     gs.pack_sparse_async(noise, stripes, records, n_dev, n_host, stream=stream)

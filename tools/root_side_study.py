@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rank 0's side of a step of the default 8-GPU run, on ONE GPU: its own shard of 384 frames (one launch),
-the background under the seven peers' rows (kifs_fill_shard_async on a second stream) and the scatter of
-their records -- alone and together.   python tools/root_side_study.py [world]"""
+the background under the seven peers' rows (kifs_fill_shard_async on a second stream; from a buffer's second
+use on only under its previous records, kifs_erase_sparse_async) and the scatter of their records -- alone
+and together.   python tools/root_side_study.py [world]"""
 import sys
 from pathlib import Path
 
@@ -56,10 +57,13 @@ def timed(label, body, reps=10):
 render = lambda: gs.render_shard_async(outs, cams, mine, in_place=True, stream=a)
 fill = lambda s: gs.fill_shard_async(frames, peers, stream=s)
 unpack = lambda s: [gs.unpack_sparse_async(frames, records, n, st1, stream=s) for _ in range(world - 1)]
+erase = lambda s: [gs.erase_sparse_async(frames, records, n, st1, stream=s) for _ in range(world - 1)]
 pack = lambda: gs.pack_sparse_async(shard, st1, records, n_dev, n_host, stream=a)
 timed("its own shard (one launch)", render)
 timed("background under the peers' rows", lambda: fill(a))
+timed("the background under the previous records only", lambda: erase(a))
 timed("scatter of the peers' records", lambda: unpack(a))
 timed("a peer's pack of its shard", pack)
 timed("shard on one stream, fill + scatter on another", lambda: (render(), fill(b), unpack(b)))
 timed("all on one stream", lambda: (render(), fill(a), unpack(a)))
+timed("shard, erase + scatter on another stream (a buffer's 2nd use)", lambda: (render(), erase(b), unpack(b)))
