@@ -80,6 +80,9 @@ def parse():
                          "the background under their rows: 'auto' (default) times, with equal shares during warm-up, "
                          "one step's rendering on rank 0, one step's gather, and the peers' side of it, and picks the "
                          "shares at which rank 0 and the peers take equally long")
+    ap.add_argument("--settle-ms", type=int, default=60,
+                    help="untimed rendering before the warm-up steps, about this many milliseconds of it (clocks and "
+                         "tile order in steady state; 0 = none)")
     ap.add_argument("--deliver", default="none", choices=["none", "root"],
                     help="N > 1, --shard frames: leave frames where they were rendered, or send them to rank 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -304,7 +307,8 @@ def main():
         pipeline.wait_all()
         torch.cuda.synchronize()
         for g in gss:
-            g.set_profiling(4)  # every 4th launch: an event pair costs a few microseconds
+            # every 4th launch: an event pair costs a few microseconds (short runs: every 2nd)
+            g.set_profiling(4 if steps >= 40 else 2)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -494,12 +498,25 @@ def main():
         pipe, step = whole_frames(B, args.camera, deliver=(args.deliver == "root"))
         frames_per_step = B * world
         rows0, frames_per_launch, launches_per_step = H, B, 1
-    m = run(pipe, step, args.steps, args.warmup)
+    # Settle (untimed, before the W warm-up steps): the device's clocks and the tile order of this geometry
+    # need some tens of milliseconds of work to reach their steady state -- more than the W = 5 steps a
+    # short run asks for (5 ms of GPU time; 20 timed steps then read 3 % low).  Steps settle_first ..: the
+    # step numbering of warm-up and timed steps continues after them.
+    # (a step count from the workload's constants, the same on every rank: a step is roughly its pixels at 60 Gpixel/s)
+    step_ms = max(0.05, frames_per_step * W * H / max(1, world) / 60.0e6)
+    settle_steps = min(400, int(-(-max(0, args.settle_ms) // step_ms)))
+    settle_steps += settle_steps % 2  # (an even number: the double buffering's slots line up as without it)
+    for k in range(settle_steps):
+        step(k)
+    pipe.wait_all()
+    torch.cuda.synchronize()
+    base_step = [settle_steps]
+    m = run(pipe, lambda k: step(k + base_step[0]), args.steps, args.warmup)
     elapsed = m["elapsed"]
 
     check = None
     if args.check:
-        last = args.warmup + args.steps - 1
+        last = settle_steps + args.warmup + args.steps - 1
         if rank == 0:
             ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
 
@@ -622,7 +639,8 @@ def main():
                        "encode": "srgb8" if args.encode else "unorm8",
                        "camera": "orbit, one pose per frame" if args.camera == "orbit" else "fixed",
                        "frames_per_step": frames_per_step, "frames_per_launch": frames_per_launch,
-                       "launches_in_flight": F, "parallelism": parallelism},
+                       "launches_in_flight": F, "parallelism": parallelism,
+                       "settle_steps_before_warmup": settle_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_source,
