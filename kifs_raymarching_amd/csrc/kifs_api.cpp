@@ -244,12 +244,15 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
         P->tile_cull_beta = (P->quick_cull_n2 > 0.0f && c->screen.height >= 64.0f) ? 34.0f / c->screen.height : 0.0f;
     }
     {   // Ray re-queuing (render_group_kernel): rounds of this many march steps -- 16 for the Julia
-        // pipeline, 8 for the others (measured; KIFS_ROUND_STEPS overrides, 0 switches it off).
+        // pipelines (generalised Julia: 1080p lone 0.882 -> 0.869 ms, x8 +2.7 %, x48 +1 % over rounds of 8),
+        // 8 for the others (measured; KIFS_ROUND_STEPS overrides, 0 switches it off).
         // Not for heatmap frames (their per-ray step count is kept by the one-wave-per-block
         // march), not with a non-positive epsilon (the queue rebuilds p from t and relies on
         // t > 0 after a step), not for marches too short to repay the rounds' barriers.
         static const int forced = tuning_knob("KIFS_ROUND_STEPS");
-        int rounds = forced >= 0 ? forced : (o.fractal_group_id == uint32_t(kifs::GROUP_JULIA) ? 16 : 8);
+        int rounds = forced >= 0 ? forced : (o.fractal_group_id != uint32_t(kifs::GROUP_KIFS) ? 16 : 8);
+        if (forced < 0 && rounds == 16 && o.max_iterations < 32 && o.fractal_group_id == uint32_t(kifs::GROUP_GENJULIA))
+            rounds = 8;  // (a short march of heavy steps still repays shorter rounds)
         if (o.is_heatmap || !(o.epsilon > 0.0f) || o.max_iterations < 2 * rounds) rounds = 0;
         P->round_steps = rounds;
     }

@@ -146,7 +146,7 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
                 assert (outs[0].cpu().numpy() == got).all()
             else:
                 got = gs.render(y0=y0, y1=y1)
-            assert gs.debug_last_round_steps() == (16 if julia else 8), scene
+            assert gs.debug_last_round_steps() == (16 if julia or scene == "genjulia" else 8), scene
             assert diff_report(got, want)["mismatched_pixels"] == 0, (scene, y0, y1)
             assert (want[..., :3] != want[0, 0, :3]).any()
     finally:
