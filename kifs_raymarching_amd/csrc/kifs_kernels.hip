@@ -894,7 +894,7 @@ constexpr int SPARSE_RECORD_WORDS = SPARSE_RECORD_WORDS_HOST;
 __global__ __launch_bounds__(256) void pack_sparse_kernel(
     const uint8_t* __restrict__ src, size_t src_pitch, size_t src_shard_stride, const uint32_t* __restrict__ stripe_rows,
     int n_stripes, int count, int width, int height, uint32_t background, uint32_t* __restrict__ records,
-    uint32_t* __restrict__ n_records) {
+    uint32_t* __restrict__ n_records, int vec16) {
     __shared__ uint32_t s_wave_count[4], s_base;
     const uint32_t tiles_x = uint32_t(width + TILE_W - 1) / TILE_W;
     const uint32_t total = uint32_t(count) * uint32_t(n_stripes) * tiles_x;
@@ -915,9 +915,14 @@ __global__ __launch_bounds__(256) void pack_sparse_kernel(
             if (row < rows) {
                 const uint32_t* from = reinterpret_cast<const uint32_t*>(src + size_t(shard) * src_shard_stride +
                                                                          (size_t(sk) * TILE_H + size_t(row)) * src_pitch) + x;
+                if (vec16 && x + 3 < width) {  // rows and pitches 16-byte aligned: one load per lane
+                    const uint4 v = *reinterpret_cast<const uint4*>(from);
+                    px[j][0] = v.x; px[j][1] = v.y; px[j][2] = v.z; px[j][3] = v.w;
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (x + q < width) px[j][q] = from[q];
+                    for (int q = 0; q < 4; ++q)
+                        if (x + q < width) px[j][q] = from[q];
+                }
             }
         }
         const bool differs = (px[j][0] != background) || (px[j][1] != background) || (px[j][2] != background) ||
@@ -998,8 +1003,10 @@ hipError_t launch_pack_sparse(const uint8_t* src, size_t src_pitch, size_t src_s
                               uint32_t* n_records, hipStream_t stream) {
     if (n_stripes <= 0 || count <= 0) return hipSuccess;
     const uint64_t tiles = uint64_t(count) * uint64_t(n_stripes) * uint64_t((width + TILE_W - 1) / TILE_W);
+    const uintptr_t all = reinterpret_cast<uintptr_t>(src) | src_pitch | src_shard_stride;
     hipLaunchKernelGGL(pack_sparse_kernel, dim3(uint32_t((tiles + 15u) / 16u)), dim3(256), 0, stream, src, src_pitch,
-                       src_shard_stride, stripe_rows, n_stripes, count, width, height, background, records, n_records);
+                       src_shard_stride, stripe_rows, n_stripes, count, width, height, background, records, n_records,
+                       (all & 15u) == 0 ? 1 : 0);
     return hipGetLastError();
 }
 
