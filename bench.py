@@ -77,9 +77,8 @@ def parse():
     ap.add_argument("--root-weight", default="auto",
                     help="N > 1, stripes: W or W:P -- rank 0 renders W stripes for every P (default 1) of a peer.  "
                          "Rank 0 also takes every peer's pixels in (each over ONE point-to-point xGMI link) and writes "
-                         "the background under their rows: 'auto' (default) times, with equal shares during warm-up, "
-                         "one step's rendering on rank 0, one step's gather, and the peers' side of it, and picks the "
-                         "shares at which rank 0 and the peers take equally long")
+                         "the background under their rows: 'auto' (default) tries a few shares on the real pipeline "
+                         "before the warm-up steps and keeps the fastest")
     ap.add_argument("--settle-ms", type=int, default=60,
                     help="untimed rendering before the warm-up steps, about this many milliseconds of it (clocks and "
                          "tile order in steady state; 0 = none)")
@@ -407,63 +406,52 @@ def main():
         sf.render = render
         return sf, step
 
+    def settle_count(frames_per_step):
+        """Steps worth about --settle-ms of rendering: from the workload's constants, the same on every rank (a
+        step is roughly its pixels at 60 Gpixel/s per GPU); an even number, so that the double buffering's slots
+        line up as without it."""
+        step_ms = max(0.05, frames_per_step * W * H / max(1, world) / 60.0e6)
+        n = min(400, int(-(-max(0, args.settle_ms) // step_ms)))
+        return n + n % 2
+
     def calibrate_root_weight(frames_per_step):
-        """Equal shares first: time rank 0's rendering of one step, one step's gather (all peers sending at once,
-        each over its own link; rank 0's fill / unpack) and what a peer spends on its side before its message is
-        out (the pack).  A rank at weight w of the total T renders s = N w / T of an equal share.  Model:
-            rank 0:  t_render s0 + t_gather (N - s0) / (N - 1)      (it fills / unpacks what it does not render)
-            a peer:  (t_render + t_pack) s1
-        and the shares (root : peer, small integers) with the smallest maximum win.  With every row crossing the
-        links (--gather dense) the gather dominates and rank 0 gets several times a peer's share; with sparse
-        shards it is rank 0's own fill that counts and the peers get more.  Rank 0 decides, everybody follows."""
-        sf, step = row_shards(frames_per_step, args.camera, contiguous=False)
-        t_render = t_gather = t_pack = 0.0
-        with torch.cuda.stream(streams[0]):
-            for k in range(2):
+        """Rank 0 : peer shares by trial, during warm-up: for a few candidate shares the real pipeline runs ten
+        steps (the last six timed: barrier, steps, wait_all, synchronise, barrier; the slowest rank counts) and
+        the fastest wins, the more even one among those within 2 %.  No model: rank 0 also takes every peer's
+        pixels in and puts the background under their rows, a peer also packs its shard, transfers overlap the
+        next step's rendering -- what that adds up to is what the trial measures.  With every row crossing the
+        links (--gather dense) rank 0 wants several times a peer's share; with sparse shards about the same."""
+        candidates = ([(1, 1), (3, 4), (4, 3), (2, 3), (3, 2), (1, 2), (2, 1)] if args.gather == "sparse"
+                      else [(1, 1), (2, 1), (3, 1), (4, 1), (6, 1), (8, 1), (12, 1), (16, 1)])
+        on = device if args.backend == "nccl" else "cpu"
+        trial = {}
+        for i, cand in enumerate(candidates):
+            sf, step = row_shards(frames_per_step, args.camera, contiguous=False, root_weight=cand)
+            # (the first trial also brings the device's clocks up: it gets the settle phase's worth of steps)
+            warm = 4 + (settle_count(frames_per_step) if i == 0 else 0)
+            for k in range(warm):
                 step(k)
             sf.wait_all()
             torch.cuda.synchronize()
-            for k in range(2, 5):
-                barrier()
-                t0 = time.perf_counter()
-                outs, in_place = sf.targets(k)
-                if sf.rows[rank] > 0:
-                    sf.render(outs, k * frames_per_step, sf.my_stripes, in_place)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                barrier()
-                t2 = time.perf_counter()
-                sf.gather_async(k)   # sparse: returns once this rank's record count is on its host (the pack is done)
-                t2b = time.perf_counter()
-                sf.wait(k)
-                torch.cuda.synchronize()
-                barrier()
-                t3 = time.perf_counter()
-                if k > 2:  # the first timed pass still warms things up
-                    t_render += (t1 - t0) / 2
-                    t_gather += (t3 - t2) / 2
-                    t_pack += (t2b - t2) / 2 if rank != 0 else 0.0
-        on = device if args.backend == "nccl" else "cpu"
-        tp = torch.tensor([t_pack], dtype=torch.float64, device=on)
-        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        t_pack = float(tp.item())
-        best = (1, 1)
-        if rank == 0:
-            candidates = [(k, 1) for k in range(1, 17)] + [(1, 2), (1, 3), (1, 4), (2, 3), (3, 4), (3, 2), (5, 2)]
-            cost = {}
-            for w0, w1 in candidates:
-                total = w0 + (world - 1) * w1
-                s0, s1 = world * w0 / total, world * w1 / total
-                cost[(w0, w1)] = max(t_render * s0 + t_gather * (world - s0) / (world - 1), (t_render + t_pack) * s1)
-            floor = min(cost.values())  # among the shares within 3 % of the best, the most even ones
-            best = min((c for c in candidates if cost[c] <= 1.03 * floor), key=lambda c: (max(c) / min(c), cost[c]))
-        t = torch.tensor(list(best), dtype=torch.int64, device=on)
-        dist.broadcast(t, src=0)
-        del sf
-        torch.cuda.empty_cache()  # the calibration's frame buffers must not sit beside the run's
-        return (int(t[0].item()), int(t[1].item())), {"render_ms_equal_shares": round(t_render * 1e3, 4),
-                                                      "gather_ms_equal_shares": round(t_gather * 1e3, 4),
-                                                      "peer_pack_ms_equal_shares": round(t_pack * 1e3, 4)}
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(warm, warm + 6):
+                step(k)
+            sf.wait_all()
+            torch.cuda.synchronize()
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / 6], dtype=torch.float64, device=on)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[cand] = float(t.item())
+            del sf, step
+            torch.cuda.empty_cache()  # the trial's frame buffers must not sit beside the next one's
+            if args.gather == "dense" and len(trial) >= 3:
+                times = list(trial.values())
+                if times[-1] > times[-2] > times[-3]:  # past the minimum: larger shares only get slower
+                    break
+        floor = min(trial.values())
+        best = min((c for c in trial if trial[c] <= 1.02 * floor), key=lambda c: (max(c) / min(c), trial[c]))
+        return best, {"ms_per_step_by_share": {f"{c[0]}:{c[1]}": round(v * 1e3, 4) for c, v in trial.items()}}
 
     # ---- the headline sequence
     sharded = world > 1 and args.shard in ("stripes", "bands")
@@ -502,10 +490,7 @@ def main():
     # need some tens of milliseconds of work to reach their steady state -- more than the W = 5 steps a
     # short run asks for (5 ms of GPU time; 20 timed steps then read 3 % low).  Steps settle_first ..: the
     # step numbering of warm-up and timed steps continues after them.
-    # (a step count from the workload's constants, the same on every rank: a step is roughly its pixels at 60 Gpixel/s)
-    step_ms = max(0.05, frames_per_step * W * H / max(1, world) / 60.0e6)
-    settle_steps = min(400, int(-(-max(0, args.settle_ms) // step_ms)))
-    settle_steps += settle_steps % 2  # (an even number: the double buffering's slots line up as without it)
+    settle_steps = settle_count(frames_per_step)
     for k in range(settle_steps):
         step(k)
     pipe.wait_all()
