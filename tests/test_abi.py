@@ -149,3 +149,19 @@ def test_bench_launches_its_own_ranks_and_reports_a_failed_rank():
     assert p.returncode != 0
     assert "no GPU visible" in p.stderr and "a rank failed" in p.stderr
     assert not any(l.startswith("{") for l in p.stdout.splitlines())
+
+
+def test_prepared_pointer_and_camera_arrays(kifs):
+    """DevicePointers and camera_array: what a step of a few hundred views hands the render calls instead of
+    Python lists (collected once per buffer slot / per sequence of poses)."""
+    import torch
+    frames = torch.zeros((5, 4, 8, 4), dtype=torch.uint8)
+    ptrs = kifs.DevicePointers([frames[i] for i in range(5)])
+    assert len(ptrs) == 5 and ptrs[3].data_ptr() == frames[3].data_ptr()
+    assert [int(v) for v in ptrs.array] == [frames[i].data_ptr() for i in range(5)]
+    cams = [kifs.CameraData(origin_distance=3.0 + k, phi=0.1 * k) for k in range(4)]
+    arr = kifs.camera_array(cams)
+    assert len(arr) == 4 and kifs.camera_array(arr) is arr
+    assert kifs.uniform_bytes(arr[2]) == kifs.uniform_bytes(cams[2].into_buffer_data())
+    mixed = kifs.camera_array([cams[0], cams[1].into_buffer_data()])
+    assert kifs.uniform_bytes(mixed[1]) == kifs.uniform_bytes(cams[1].into_buffer_data())
