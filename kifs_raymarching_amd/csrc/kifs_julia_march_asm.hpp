@@ -1,5 +1,5 @@
 // The asm statement of julia_fast_march (kifs_scene.hpp), included once per variant with
-// KIFS_JULIA_DIVSQRT / KIFS_JULIA_DIVSQRT_OUT_OF_LINE, KIFS_FAST_TRIP / KIFS_TRIP_EXIT / KIFS_JULIA_PROLOGUE /
+// KIFS_JULIA_DIVSQRT / KIFS_JULIA_DIVSQRT_OUT_OF_LINE, KIFS_FAST_TRIP / KIFS_TRIP_EXIT / KIFS_TRIP_EXIT_BACK / KIFS_JULIA_PROLOGUE /
 // KIFS_JULIA_C_OPERANDS defined by the includer.  See the
 // register map and the description there.
     asm volatile(
@@ -103,7 +103,7 @@
         "30:\n"
         "s_mov_b32 s97, %[rem]\n"
         "31:\n"
-        KIFS_FAST_TRIP
+        KIFS_FAST_TRIP KIFS_TRIP_EXIT_BACK
         "s_sub_u32 s97, s97, 1\n"
         "s_cmp_lg_u32 s97, 0\n"
         "s_cbranch_scc1 31b\n"

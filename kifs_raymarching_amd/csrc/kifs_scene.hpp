@@ -661,6 +661,7 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
     if constexpr (THROUGHPUT) {
 #define KIFS_FAST_TRIP KIFS_FAST_TRIP_SCALAR
 #define KIFS_TRIP_EXIT "s_cbranch_execz 14f\n"  /* scalar slots are free where the vector pipe is the limit: test every trip */
+#define KIFS_TRIP_EXIT_BACK "s_cbranch_execz 14b\n"  /* the same from the remainder trips, which sit BEHIND label 14 */
 #define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_SCALAR
 #define KIFS_JULIA_C_OPERANDS [cy] "s"(P.c.y), [cz] "s"(P.c.z), [cw] "s"(P.c.w), [cx] "s"(P.c.x)
         if constexpr (SHORT_DIVSQRT) {
@@ -678,12 +679,14 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
         }
 #undef KIFS_FAST_TRIP
 #undef KIFS_TRIP_EXIT
+#undef KIFS_TRIP_EXIT_BACK
 #undef KIFS_JULIA_PROLOGUE
 #undef KIFS_JULIA_C_OPERANDS
     } else {
         const F2 cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x};
 #define KIFS_FAST_TRIP KIFS_FAST_TRIP_PACKED
 #define KIFS_TRIP_EXIT  /* a lone wave pays for every instruction: test every third trip only */
+#define KIFS_TRIP_EXIT_BACK
 #define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_PACKED
 #define KIFS_JULIA_C_OPERANDS [cyz] "s"(cyz), [cw0] "s"(cw0), [c0x] "s"(c0x)
         if constexpr (SHORT_DIVSQRT) {
@@ -701,6 +704,7 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
         }
 #undef KIFS_FAST_TRIP
 #undef KIFS_TRIP_EXIT
+#undef KIFS_TRIP_EXIT_BACK
 #undef KIFS_JULIA_PROLOGUE
 #undef KIFS_JULIA_C_OPERANDS
     }
