@@ -10,8 +10,10 @@ destination per frame, packed by the host camera model exactly as the reference 
 BASELINE.json's metric configuration: 1920x1080 quaternion-Julia, 256 march steps, 12 SDF
 iterations.  Rank 0 prints ONE JSON line; besides the headline it carries, measured in the same
 process after the timed region, `secondary.lone_frame` (one frame per launch: the latency path),
-`secondary.orbit_x8` (8 frames per launch) and `secondary.fixed_camera` (the same view in all 8 slots
-of a batch: round 1's headline, the most favourable case for the tile-order feedback).
+`secondary.orbit_x8` (8 frames per launch), `secondary.fixed_camera` (the same view in all 8 slots
+of a batch: round 1's headline, the most favourable case for the tile-order feedback) and, for the headline
+workload, the north star's other sizes: `secondary.cfg4_julia_4096` (4096 x 4096, 512 / 16; batched and lone) and
+`secondary.ref_constants_1080p` (the reference's hard-coded 100 / 10 iterations and GUI-default constant).
 
 N > 1 (one process per GPU; `python bench.py --gpus N` launches the N ranks itself, or it runs
 under torch.distributed.run): the north star's path.  Every frame is split into ROW SHARDS --
@@ -24,6 +26,11 @@ frames-per-launch frames' worth of pixels per step (`--scaling strong` fixes the
 frames-per-launch frames instead).  `--shard bands` uses contiguous runs of stripes,
 `--shard frames` whole frames per rank (no exchange unless `--deliver root`); the latter is also
 measured after the timed region and reported as `secondary.frame_parallel`.
+
+`--host one-process` (N > 1): the form the reference's own host would use -- ONE process and one thread drive all N
+devices through the C ABI's kifs_multi_render_batch_async (sparse records gathered by RCCL grouped send/recv inside
+the library, two steps in flight); the JSON line has the same shape.  `--whole-orbit`: a step is the workload's whole
+orbit (120 frames for cfg5) in launches of --frames-per-launch frames, every frame resident in HBM.
 
 There are no HBM-resident inputs beyond the 156 uniform bytes; the output frames live in HBM
 (torch tensors) and are written by the kernel.  `roofline` prices the dominant kernel against
@@ -90,6 +97,16 @@ def parse():
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region, compare rank 0's gathered frames with single-GPU renders")
+    ap.add_argument("--no-check", action="store_true",
+                    help="N > 1: skip the default comparison of the last step's gathered frames with single-GPU renders")
+    ap.add_argument("--host", default="per-gpu", choices=["per-gpu", "one-process"],
+                    help="N > 1: one process per GPU over torch.distributed (default, the driver's launch), or ONE process "
+                         "driving all N devices through kifs_multi_render_batch_async (RCCL inside the library)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "copy"],
+                    help="--host one-process: the library's transport (auto = RCCL on distinct devices, peer copies otherwise)")
+    ap.add_argument("--whole-orbit", action="store_true",
+                    help="N = 1: a step is the workload's WHOLE orbit (max(frames, 120) poses, every frame resident in HBM) "
+                         "in launches of --frames-per-launch frames")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
     return ap.parse_args()
 
@@ -226,11 +243,213 @@ def pmc_traffic(workload_key, frames_per_launch=1):
     except (OSError, ValueError, KeyError):
         return None, None, None
 
+def measure_workload(name, local_rank, B, steps, warmup, encode, camera_mode="orbit", settle_ms=30.0):
+    """One more workload in the same process, after the timed region: its own context, stream and buffers; `steps`
+    launches of B frames of its orbit; wall clock around the loop and the library's per-launch event pairs."""
+    import torch
+
+    import kifs_raymarching_amd as K
+    from kifs_raymarching_amd.configs import WORKLOADS, orbit_camera
+
+    w = WORKLOADS[name]
+    W, H = w.screen.width, w.screen.height
+    device = torch.device("cuda", local_rank)
+    g = K.GraphicState(local_rank, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui)
+    g.set_iters(*w.iters)
+    if w.extensions:
+        g.set_extensions(**w.extensions)
+    stream = torch.cuda.Stream(device=device)
+    bufs = [torch.zeros((B * H, W, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+    n_poses = max(w.frames, 120)
+    poses = ([orbit_camera(w, i).into_buffer_data() for i in range(n_poses)] if camera_mode == "orbit"
+             else [w.camera.into_buffer_data()])
+    arrays = {}
+
+    def cams(first):
+        key_ = first % len(poses)
+        if key_ not in arrays:
+            arrays[key_] = K.camera_array([poses[(first + i) % len(poses)] for i in range(B)])
+        return arrays[key_]
+
+    def step(k):
+        out = bufs[k % 2]
+        with torch.cuda.stream(stream):
+            if B == 1:
+                g.set_raw_uniforms(camera=cams(k)[0])
+                g.render_async(out, stream=stream, y0=0, y1=H, encode=encode)
+            else:
+                g.render_batch_async([out[i * H:(i + 1) * H] for i in range(B)], cams(k * B), stream=stream,
+                                     y0=0, y1=H, encode=encode)
+    t_settle = time.perf_counter()
+    k = 0
+    while k < warmup or (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+        step(k)
+        k += 1
+        if k % 8 == 0:
+            stream.synchronize()
+    stream.synchronize()
+    g.set_profiling(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(steps):
+        step(k + j)
+    stream.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n, mean_ms, lo, hi = g.profile_read()
+    g.set_profiling(0)
+    shape = ("render_wave_kernel" if g.debug_last_round_steps() > 0 and g.debug_last_group_tiles() == 0 else
+             "render_group_kernel" if g.debug_last_round_steps() > 0 else "render_kernel")
+    g.close()
+    del bufs
+    torch.cuda.empty_cache()
+    ms = elapsed / steps * 1e3
+    k_ms = mean_ms if n else ms
+    return {"workload": name, "width": W, "height": H, "frames_per_launch": B, "steps": steps,
+            "ms_per_step": round(ms, 5), "ms_per_frame": round(ms / B, 5),
+            "mpix_s": round(B * W * H / (ms * 1e-3) / 1e6, 2), "kernel": shape, "kernel_ms": round(k_ms, 5),
+            "hbm_frac": round(B * 4.0 * W * H / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+
+
+def one_process(args):
+    """--host one-process: this process alone drives all N devices through kifs_multi_render_batch_async -- what the
+    reference's single-process host (application.rs:37-48) would call.  Same protocol and JSON shape as the
+    per-GPU form: settle, W warm-up steps, exactly K timed steps between synchronisations, frames gathered on device 0."""
+    import torch
+
+    import kifs_raymarching_amd as K
+    from kifs_raymarching_amd.configs import HEADLINE, WORKLOADS, orbit_camera
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the render path has no CPU fallback")
+    N = args.gpus
+    have = torch.cuda.device_count()
+    devices = [0] * N if args.share_device else list(range(N))
+    if not args.share_device and have < N:
+        sys.exit(f"bench.py: --host one-process --gpus {N} needs {N} devices, {have} visible (--share-device rehearses on one)")
+    key = args.workload or HEADLINE
+    w = WORKLOADS[key]
+    W, H = w.screen.width, w.screen.height
+    B = max(1, min(args.frames_per_launch, K.MAX_BATCH))
+    fps = B * N if args.scaling == "weak" else B
+    fps = max(1, min(fps, K.MAX_BATCH, int(24e9 // (2 * 4 * W * H))))
+    torch.cuda.set_device(0)
+    dev0 = torch.device("cuda", 0)
+    mg = K.MultiGraphicState(devices, w.screen, w.camera, w.gui, iters=w.iters)
+    if w.extensions:
+        mg.set_extensions(**w.extensions)
+    mg.set_gather(args.gather, args.transport)
+    weights = None
+    if args.root_weight not in ("auto", "1", "1:1"):
+        parts = [max(1, int(x)) for x in str(args.root_weight).split(":")]
+        weights = [parts[0]] + [parts[1] if len(parts) > 1 else 1] * (N - 1)
+        mg.set_weights(weights)
+    frames = [torch.zeros((fps, H, W, 4), dtype=torch.uint8, device=dev0) for _ in range(2)]
+    n_poses = max(w.frames, 120)
+    poses = ([orbit_camera(w, i).into_buffer_data() for i in range(n_poses)] if args.camera == "orbit"
+             else [w.camera.into_buffer_data()])
+    arrays = {}
+
+    def cams(first):
+        key_ = first % len(poses)
+        if key_ not in arrays:
+            if len(arrays) > 64:
+                arrays.clear()
+            arrays[key_] = K.camera_array([poses[(first + i) % len(poses)] for i in range(fps)])
+        return arrays[key_]
+
+    def step(k):
+        return mg.render_batch_async(frames[k % 2], cams(k * fps), encode=args.encode, untouched=k >= 2)
+
+    step_ms = max(0.05, fps * W * H / N / 60.0e6)
+    settle = min(400, int(-(-max(0, args.settle_ms) // step_ms)))
+    settle += settle % 2
+    for k in range(settle + args.warmup):
+        step(k)
+    mg.wait_all()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    mg.stats(reset=True)
+    base = settle + args.warmup
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(base + k)
+    mg.wait_all()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    stats = mg.stats()
+    shards = mg.shards()
+    check = None
+    if not args.no_check:
+        last = base + args.steps - 1
+        got = frames[last % 2]
+        ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev0)
+        with K.GraphicState(0, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui) as g1:
+            g1.set_iters(*w.iters)
+            if w.extensions:
+                g1.set_extensions(**w.extensions)
+            arr = cams(last * fps)
+            check = True
+            for i in range(fps):
+                g1.set_raw_uniforms(camera=arr[i])
+                g1.render(out=ref, encode=args.encode)
+                if not bool(torch.equal(got[i], ref)):
+                    check = False
+                    break
+    mpix = fps * W * H * args.steps / elapsed / 1e6
+    rows0 = shards[0][2]
+    k_ms = shards[0][3] if shards[0][3] > 0 else elapsed / args.steps * 1e3
+    alg_bytes = 4.0 * W * rows0 * fps
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    out = {
+        "metric": METRIC, "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": N, "steps": args.steps,
+        "warmup": args.warmup, "settle_steps": settle, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "strong" if args.scaling == "strong" else "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": key, "description": w.name, "width": W, "height": H,
+                   "max_iterations": w.gui.max_iterations, "sdf_iters": w.iters[0], "normal_iters": w.iters[1],
+                   "fold_iters": w.iters[2], "encode": "srgb8" if args.encode else "unorm8",
+                   "camera": "orbit, one pose per frame" if args.camera == "orbit" else "fixed",
+                   "frames_per_step": fps, "frames_per_launch": fps, "launches_in_flight": 1,
+                   "host": "one process, one thread, kifs_multi_render_batch_async (C ABI)",
+                   "parallelism": (f"{N} devices {devices} driven by ONE process: row shards (8-row stripes dealt round-robin"
+                                   + (f", weights {weights}" if weights else "") + f") of {fps} frames per step, one launch "
+                                   "per device, gathered on device 0 " +
+                                   ("as sparse records of the 32x8 tiles that hold something" if args.gather == "sparse" else "dense")
+                                   + f" by {'RCCL grouped ncclSend/ncclRecv inside the library' if stats['transport'] == 'rccl' else 'peer copies (hipMemcpyPeerAsync)'}"),
+                   "settle_steps_before_warmup": settle, "gather": args.gather,
+                   "rows_per_rank": [sh[2] for sh in shards]},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "traffic_source": None,
+                     "kernel": "render_wave_kernel", "kernel_ms": round(k_ms, 5), "launches_timed": 1,
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "note": "device 0's launch of the last step (event pair around its render kernel)"},
+        "per_rank_kernel_ms": [round(sh[3], 5) for sh in shards],
+        "comm": {"backend": "rccl (in-library, ncclCommInitAll)" if stats["transport"] == "rccl" else "hip peer copies",
+                 "world_size_seen": stats["comm_ranks"] if stats["transport"] == "rccl" else len(set(devices)),
+                 "rccl_version": stats["rccl_version"], "gather": stats["gather"], "check": check,
+                 "bytes_into_root_per_step": int(stats["bytes_received"] / max(1, stats["steps"])),
+                 "tiles_sent_fraction": (round(stats["records_received"] / stats["tiles_covered"], 4)
+                                         if stats["tiles_covered"] else None)},
+    }
+    if check is not None:
+        out["gathered_frame_equals_single_gpu_frame"] = check
+    print(json.dumps(out), flush=True)
+    mg.close()
+    if check is False:
+        sys.exit("bench.py: gathered frames differ from single-GPU frames")
+
 
 def main():
     args = parse()
     if args.orbit:
         args.camera = "orbit"
+    if args.gpus > 1 and args.host == "one-process":
+        # one process for the whole node: under a launcher every rank but the first has nothing to do
+        if int(os.environ.get("RANK", "0")) == 0:
+            one_process(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
 
@@ -350,6 +569,31 @@ def main():
             with torch.cuda.stream(streams[cur[0]]):
                 fs.step(k, render)
         return fs, step
+
+    def whole_orbit(frames_per_launch):
+        """A step = every pose of the workload's orbit once (BASELINE cfg 5: the 120-frame orbit), each frame in its
+        own resident buffer, in launches of `frames_per_launch` frames on one stream."""
+        b = frames_per_launch
+        buf = torch.zeros((orbit_len * H, W, 4), dtype=torch.uint8, device=device)
+
+        class Resident:
+            frames = buf
+
+            @staticmethod
+            def wait_all():
+                pass
+
+        def step(k):
+            with torch.cuda.stream(streams[0]):
+                for a in range(0, orbit_len, b):
+                    m_ = min(b, orbit_len - a)
+                    if m_ == 1:
+                        gs.set_raw_uniforms(camera=cameras(a, 1, "orbit")[0])
+                        gs.render_async(buf[a * H:(a + 1) * H], stream=streams[0], y0=0, y1=H, encode=args.encode)
+                    else:
+                        gs.render_batch_async([buf[(a + i) * H:(a + i + 1) * H] for i in range(m_)],
+                                              cameras(a, m_, "orbit"), stream=streams[0], y0=0, y1=H, encode=args.encode)
+        return Resident, step
 
     def row_shards(frames_per_step, camera_mode, contiguous, root_weight=(1, 1)):
         """The north star's path: every rank renders its row shard of the step's frames (launches of
@@ -482,6 +726,10 @@ def main():
         rows0 = pipe.rows[rank]
         frames_per_launch = min(frames_per_step, K.MAX_BATCH)
         launches_per_step = -(-frames_per_step // K.MAX_BATCH)
+    elif args.whole_orbit and world == 1:
+        pipe, step = whole_orbit(B)
+        frames_per_step = orbit_len
+        rows0, frames_per_launch, launches_per_step = H, B, -(-orbit_len // B)
     else:
         pipe, step = whole_frames(B, args.camera, deliver=(args.deliver == "root"))
         frames_per_step = B * world
@@ -490,7 +738,7 @@ def main():
     # need some tens of milliseconds of work to reach their steady state -- more than the W = 5 steps a
     # short run asks for (5 ms of GPU time; 20 timed steps then read 3 % low).  Steps settle_first ..: the
     # step numbering of warm-up and timed steps continues after them.
-    settle_steps = settle_count(frames_per_step)
+    settle_steps = settle_count(frames_per_step) if not args.whole_orbit else 2
     for k in range(settle_steps):
         step(k)
     pipe.wait_all()
@@ -500,7 +748,7 @@ def main():
     elapsed = m["elapsed"]
 
     check = None
-    if args.check:
+    if args.check or (world > 1 and not args.no_check):
         last = settle_steps + args.warmup + args.steps - 1
         if rank == 0:
             ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
@@ -549,6 +797,18 @@ def main():
                 secondary["fixed_camera"] = summarise(
                     run(p3, s3, sec_steps, sec_warm), 8, sec_steps,
                     "8 copies of the workload's view per launch (round 1's headline): the best case of the tile-order feedback")
+            if key == HEADLINE and not args.whole_orbit:
+                # the north star also asks for 4096 x 4096 (BASELINE cfg 4: 512 steps / 16 iterations) and every report
+                # carries the reference's own constants (100 / 10, GUI-default c): measured here, in the driver's run
+                torch.cuda.empty_cache()
+                short = max(8, min(args.steps, 24))
+                secondary["cfg4_julia_4096"] = {
+                    "batched": measure_workload("cfg4_julia_4096", local_rank, 16, short, 4, args.encode),
+                    "lone_frame": measure_workload("cfg4_julia_4096", local_rank, 1, max(20, min(args.steps, 60)), 6, args.encode),
+                    "note": "4096x4096 quaternion-Julia, 512 march steps, 16 SDF iterations, orbit camera; hbm_frac = 4 B per "
+                            "pixel / kernel time / 8 TB/s"}
+                secondary["ref_constants_1080p"] = measure_workload("ref_julia_1080p", local_rank, 48, sec_steps, sec_warm,
+                                                                    args.encode)
         elif args.shard != "frames":
             p4, s4 = whole_frames(B, args.camera, deliver=False)
             mm = run(p4, s4, sec_steps, sec_warm)
@@ -612,6 +872,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "strong" if (sharded and args.scaling == "strong") else "weak",
@@ -637,6 +898,17 @@ def main():
             "per_rank_kernel_ms": [round(x, 5) for x in per_rank_kernel_ms],
             "per_rank_step_ms": [round(x, 5) for x in per_rank_step_ms],
         }
+        if world > 1:
+            out["comm"] = {"backend": ("rccl (torch.distributed backend 'nccl')" if args.backend == "nccl" else "gloo (rehearsal)"),
+                           "world_size_seen": dist.get_world_size(),
+                           "count_channel": (None if not (sharded and args.gather == "sparse") else
+                                             "gloo side group" if count_group is not None else "device all_gather"),
+                           "gather": args.gather if sharded else ("frames to root" if args.deliver == "root" else "none"),
+                           "check": check}
+        if args.whole_orbit:
+            out["config"]["whole_orbit"] = {"frames": orbit_len, "launches_per_step": launches_per_step,
+                                            "total_ms": round(elapsed / args.steps * 1e3, 4),
+                                            "resident_bytes": int(4 * W * H * orbit_len)}
         if sharded:
             out["config"]["root_weight"] = root_weight[0]
             out["config"]["peer_weight"] = root_weight[1]

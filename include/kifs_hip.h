@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define KIFS_ABI_VERSION 2
+#define KIFS_ABI_VERSION 3
 
 /* ---- uniform images (data.rs:17-49) --------------------------------------- */
 
@@ -97,7 +97,7 @@ typedef enum KifsStatus {
     KIFS_ERR_BAD_SIZE = 3,     /* ~ RenderError::SurfaceMissized; zero size (render.rs:211) */
     KIFS_ERR_UNCONFIGURED = 4, /* render before all three uniforms were set */
     KIFS_ERR_RUNTIME = 5,      /* HIP error: fatal for the context */
-    KIFS_ERR_COMM = 6,         /* an inter-GPU transfer failed (kifs_multi_render's peer copies) */
+    KIFS_ERR_COMM = 6,         /* an inter-GPU transfer failed: RCCL (init, group, send/recv) or a peer copy */
     KIFS_ERR_BAD_ARG = 7       /* null pointer, unknown enum value, bad range */
 } KifsStatus;
 
@@ -286,6 +286,70 @@ int kifs_multi_render(kifs_multi* m, uint8_t* out_rgba8, size_t pitch_bytes, int
 int kifs_multi_shard(kifs_multi* m, int i, int* device_ordinal, int* n_stripes, int* rows);
 /* Kernel time of shard i in the last kifs_multi_render, ms (load balance across devices). */
 double kifs_multi_shard_ms(kifs_multi* m, int i);
+
+/* ---- batches of frames over several devices, gathered on the root (SURVEY 8b `kifs_render_multi`, 8e) ---------
+ * The throughput form of kifs_multi_render for the one caller the reference has (one process, one thread:
+ * application.rs:37-48, graphics.rs:310-325): `count` frames (cameras[i]; screen, options, iteration counts and
+ * extensions as set) are rendered as ONE launch per device -- each device its row shard of every frame -- and
+ * collected into `dev_frames` on the root device: frame i at dev_frames + i * frame_stride, rows frame_pitch
+ * apart (caller-owned memory of the ROOT device, free to be overwritten when the call is made).
+ *
+ *   gather     KIFS_GATHER_SPARSE (default): the other devices send only the 32 x 8 tiles that hold a pixel
+ *              other than the background (kifs_pack_sparse_async's records), the root writes the background
+ *              under their rows itself and scatters the records over it.  KIFS_GATHER_DENSE: every row.
+ *   transport  KIFS_TRANSPORT_RCCL: RCCL inside the library -- ncclCommInitAll over the listed devices once,
+ *              then per step ONE group of point-to-point transfers, `ncclGroupStart(); every other device:
+ *              ncclSend(its records, root); root: ncclRecv per device; ncclGroupEnd()` (RCCL has no gather;
+ *              each sender -> root pair rides its own xGMI link).  librccl.so.1 is opened on first use; a
+ *              device listed twice, a missing library or a failing call gives KIFS_ERR_COMM.
+ *              KIFS_TRANSPORT_COPY: hipMemcpyPeerAsync per device (the copy engines; the only form that works
+ *              with a device listed more than once, i.e. for testing on one GPU).
+ *              KIFS_TRANSPORT_AUTO (default): RCCL when every listed device is distinct and there are at
+ *              least two, else COPY.
+ *
+ * Asynchronous, two steps deep: kifs_multi_render_batch_async returns once the step's launches are enqueued
+ * and writes the step's number to *step (0, 1, 2, ..).  A step's transfers are posted when the NEXT step has
+ * been enqueued (their sizes are known on the host only once the senders have packed, and by then every device
+ * is already rendering the next step), or by a wait.  kifs_multi_wait blocks until the frames of `step` are
+ * complete in their dev_frames; kifs_multi_stream_wait makes a stream of the root device wait for them instead.
+ * At most two steps are in flight: submitting step k first completes step k - 2.  A consumer therefore reads
+ * the frames of step k after kifs_multi_wait(m, k) and before it hands the same buffer back in a later call.
+ *
+ * flags: KIFS_MULTI_FRAMES_UNTOUCHED -- dev_frames is the buffer of the submission two steps ago (same
+ * pointer, pitch, stride, count, encoding) and nothing but this library has written to it since: with the sparse
+ * gather the root then restores the background only under that step's records instead of under every row of
+ * the other devices.  Without the flag (or when anything differs, the options' background included) every such
+ * row is filled.  Each frame is bit-identical to the frame a single device renders.
+ * kifs_multi_render_batch = submit + wait. */
+typedef enum KifsGather { KIFS_GATHER_SPARSE = 0, KIFS_GATHER_DENSE = 1 } KifsGather;
+typedef enum KifsTransport { KIFS_TRANSPORT_AUTO = 0, KIFS_TRANSPORT_RCCL = 1, KIFS_TRANSPORT_COPY = 2 } KifsTransport;
+#define KIFS_MULTI_FRAMES_UNTOUCHED 1
+int kifs_multi_set_gather(kifs_multi* m, int gather, int transport);
+int kifs_multi_render_batch_async(kifs_multi* m, int count, const KifsCameraUniform* cameras, uint8_t* dev_frames,
+                                  size_t frame_pitch, size_t frame_stride, int encode, int flags, uint64_t* step);
+int kifs_multi_wait(kifs_multi* m, uint64_t step);
+int kifs_multi_wait_all(kifs_multi* m);
+int kifs_multi_stream_wait(kifs_multi* m, uint64_t step, void* hip_stream);
+int kifs_multi_render_batch(kifs_multi* m, int count, const KifsCameraUniform* cameras, uint8_t* dev_frames,
+                            size_t frame_pitch, size_t frame_stride, int encode);
+/* What the gather moved since creation (or the last call with reset != 0): steps completed, records received
+ * and the tiles they stand for (sparse), payload bytes into the root, and the transport in use
+ * (KIFS_TRANSPORT_RCCL / _COPY; AUTO until the first step decides). */
+typedef struct KifsMultiStats {
+    uint64_t steps;
+    uint64_t records_received;
+    uint64_t tiles_covered;
+    uint64_t bytes_received;
+    int32_t transport;
+    int32_t gather;
+    int32_t rccl_version; /* ncclGetVersion, 0 if RCCL was never opened */
+    int32_t comm_ranks;   /* ranks of the communicator, 0 if none */
+} KifsMultiStats;
+int kifs_multi_stats(kifs_multi* m, KifsMultiStats* out, int reset);
+/* Transport check: every other device sends `bytes` of a known pattern to the root through the configured
+ * transport exactly as a step's gather would (with one device: the root sends to itself and receives from
+ * itself in one group) and the root verifies what arrived.  KIFS_ERR_COMM on any mismatch or failing call. */
+int kifs_multi_comm_selftest(kifs_multi* m, size_t bytes);
 
 /* Device time of the most recent kifs_render on this context in ms (HIP events
  * on the launch stream), or a negative value if none completed. */

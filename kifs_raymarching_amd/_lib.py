@@ -55,6 +55,16 @@ class CameraDataC(C.Structure):  # KifsCameraData
                 ("phi", C.c_float), ("theta", C.c_float)]
 
 
+class MultiStatsC(C.Structure):  # KifsMultiStats
+    _fields_ = [("steps", C.c_uint64), ("records_received", C.c_uint64), ("tiles_covered", C.c_uint64),
+                ("bytes_received", C.c_uint64), ("transport", C.c_int32), ("gather", C.c_int32),
+                ("rccl_version", C.c_int32), ("comm_ranks", C.c_int32)]
+
+
+GATHER_SPARSE, GATHER_DENSE = 0, 1
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
+MULTI_FRAMES_UNTOUCHED = 1
+
 assert C.sizeof(ScreenUniform) == 12
 assert C.sizeof(CameraUniform) == 64
 assert C.sizeof(OptionsUniform) == 80
@@ -102,6 +112,15 @@ SIGNATURES = {
     "kifs_multi_set_weights": (C.c_int, [_ctx, _P(C.c_int)]),
     "kifs_multi_shard": (C.c_int, [_ctx, C.c_int, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "kifs_multi_shard_ms": (C.c_double, [_ctx, C.c_int]),
+    "kifs_multi_set_gather": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "kifs_multi_render_batch_async": (C.c_int, [_ctx, C.c_int, _P(CameraUniform), C.c_void_p, C.c_size_t, C.c_size_t,
+                                                C.c_int, C.c_int, _P(C.c_uint64)]),
+    "kifs_multi_wait": (C.c_int, [_ctx, C.c_uint64]),
+    "kifs_multi_wait_all": (C.c_int, [_ctx]),
+    "kifs_multi_stream_wait": (C.c_int, [_ctx, C.c_uint64, C.c_void_p]),
+    "kifs_multi_render_batch": (C.c_int, [_ctx, C.c_int, _P(CameraUniform), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
+    "kifs_multi_stats": (C.c_int, [_ctx, _P(MultiStatsC), C.c_int]),
+    "kifs_multi_comm_selftest": (C.c_int, [_ctx, C.c_size_t]),
     "kifs_last_kernel_ms": (C.c_double, [_ctx]),
     "kifs_synchronize": (C.c_int, [_ctx]),
     "kifs_set_profiling": (C.c_int, [_ctx, C.c_int]),
@@ -172,7 +191,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.kifs_abi_version() != 2:
+    if lib.kifs_abi_version() != 3:
         raise ImportError("libkifs_hip.so: ABI version mismatch")
     return lib
 

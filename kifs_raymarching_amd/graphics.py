@@ -349,6 +349,24 @@ class GraphicState:
                 raise ValueError("render_shard_async: pass a non-default torch.cuda.Stream")
         n = len(outs)
         cams = camera_array(cameras)
+        # The library knows nothing about the size of the destinations: a packed shard needs rows * pitch bytes, a
+        # shard rendered in place a whole frame.  (A DevicePointers remembers what it has been checked against: a
+        # step of a few hundred views must not pay for the check every time.)
+        h = self.screen_data.height
+        if any(s < 0 or s * STRIPE_ROWS >= h for s in stripes):
+            raise ValueError("render_shard_async: stripe outside the frame")
+        need_rows = h if in_place else sum(min(STRIPE_ROWS, h - s * STRIPE_ROWS) for s in stripes)
+        need = ((need_rows - 1) * pitch + w * 4) if need_rows else 0
+        checked = getattr(outs, "checked_bytes", None)
+        if checked is None or checked < need:
+            for o in (outs.tensors if isinstance(outs, DevicePointers) else outs):
+                if hasattr(o, "element_size"):
+                    if not o.is_contiguous() or o.element_size() != 1 or o.numel() < need:
+                        raise ValueError(f"render_shard_async: every destination must be a contiguous uint8 tensor of at "
+                                         f"least {need} bytes ({need_rows} rows of pitch {pitch}"
+                                         f"{', a whole frame: in_place' if in_place else ''}); got {tuple(o.shape)}")
+            if isinstance(outs, DevicePointers):
+                outs.checked_bytes = need
         ptrs = outs.array if isinstance(outs, DevicePointers) else (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
         st = _stripe_array(stripes)
         check(lib.kifs_render_shard_async(self._ctx, stream, n, cams, ptrs, pitch, st, len(st),
@@ -538,8 +556,11 @@ class GraphicState:
 
 
 class MultiGraphicState:
-    """Single-process multi-GPU renderer over kifs_multi_* (one context per device, 8-row stripes
-    dealt to the devices, shards collected on the first device by peer-to-peer copies)."""
+    """Single-process multi-GPU renderer over kifs_multi_* -- what the reference's one-process host would hold
+    in place of its GraphicState (graphics.rs:25-37) on a node with several GPUs: one context per device, 8-row
+    stripes dealt to the devices, shards collected on the first device.  render(): one frame, dense, synchronous.
+    render_batch_async() / wait(): steps of up to 512 frames, sparse records over RCCL grouped send/recv inside
+    the library, two steps in flight."""
 
     def __init__(self, devices, screen_data: ScreenData, camera_data: CameraData = None,
                  gui_data: GuiData = None, iters=(100, 10, 10)):
@@ -573,6 +594,70 @@ class MultiGraphicState:
         ptr = out.ctypes.data if isinstance(out, np.ndarray) else _device_pointer(out)
         check(lib.kifs_multi_render(self._m, ptr, pitch_bytes or w * 4, encode), "multi render")
         return out
+
+    # ---- batches of frames, gathered on the first device (kifs_multi_render_batch_async) ----------------
+    def set_extensions(self, soft_shadow=False, shadow_steps=0, shadow_k=0.0, shadow_t0=0.0, shadow_max_t=0.0):
+        e = ExtensionsC(1 if soft_shadow else 0, int(shadow_steps), float(shadow_k), float(shadow_t0), float(shadow_max_t))
+        check(lib.kifs_multi_set_extensions(self._m, C.byref(e)), "multi set_extensions")
+
+    def set_gather(self, gather: str = "sparse", transport: str = "auto"):
+        """gather: 'sparse' (the other devices send only the tiles that hold something) or 'dense';
+        transport: 'auto', 'rccl' (grouped ncclSend / ncclRecv inside the library) or 'copy' (peer copies)."""
+        g = {"sparse": _lib.GATHER_SPARSE, "dense": _lib.GATHER_DENSE}[gather]
+        t = {"auto": _lib.TRANSPORT_AUTO, "rccl": _lib.TRANSPORT_RCCL, "copy": _lib.TRANSPORT_COPY}[transport]
+        check(lib.kifs_multi_set_gather(self._m, g, t), f"multi set_gather({gather}, {transport})")
+
+    def _frames_args(self, frames, cameras):
+        w, h = self.screen_data.width, self.screen_data.height
+        if (frames.dim() != 4 or tuple(frames.shape[1:]) != (h, w, 4) or frames.element_size() != 1
+                or not frames.is_contiguous()):
+            raise ValueError(f"render_batch: frames (count, {h}, {w}, 4) uint8, contiguous, on the first listed device")
+        cams = camera_array(cameras)
+        if len(cams) != int(frames.shape[0]) or not 1 <= len(cams) <= MAX_BATCH:
+            raise ValueError(f"render_batch: {int(frames.shape[0])} frames for {len(cams)} cameras (1..{MAX_BATCH})")
+        if frames.is_cuda and frames.device.index not in (None, self.devices[0]):
+            raise ValueError("render_batch: frames must live on the first listed device (the root of the gather)")
+        return len(cams), cams, _device_pointer(frames), w * 4, h * w * 4
+
+    def render_batch_async(self, frames, cameras, encode: int = ENCODE_SRGB, untouched: bool = False) -> int:
+        """Submits one step: frames[i] (a (count, H, W, 4) uint8 tensor on the first listed device) <- cameras[i].
+        Returns the step number for wait() / stream_wait().  untouched=True: `frames` is the buffer passed two
+        steps ago and nothing else wrote to it since (KIFS_MULTI_FRAMES_UNTOUCHED)."""
+        n, cams, ptr, pitch, stride = self._frames_args(frames, cameras)
+        step = C.c_uint64(0)
+        check(lib.kifs_multi_render_batch_async(self._m, n, cams, ptr, pitch, stride, encode,
+                                                _lib.MULTI_FRAMES_UNTOUCHED if untouched else 0, C.byref(step)),
+              "multi render_batch_async")
+        return int(step.value)
+
+    def render_batch(self, frames, cameras, encode: int = ENCODE_SRGB):
+        n, cams, ptr, pitch, stride = self._frames_args(frames, cameras)
+        check(lib.kifs_multi_render_batch(self._m, n, cams, ptr, pitch, stride, encode), "multi render_batch")
+        return frames
+
+    def wait(self, step: int):
+        check(lib.kifs_multi_wait(self._m, int(step)), f"multi wait({step})")
+
+    def wait_all(self):
+        check(lib.kifs_multi_wait_all(self._m), "multi wait_all")
+
+    def stream_wait(self, step: int, stream):
+        handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else stream
+        if not handle:
+            raise ValueError("stream_wait: pass a non-default torch.cuda.Stream")
+        check(lib.kifs_multi_stream_wait(self._m, int(step), handle), f"multi stream_wait({step})")
+
+    def stats(self, reset: bool = False) -> dict:
+        st = _lib.MultiStatsC()
+        check(lib.kifs_multi_stats(self._m, C.byref(st), 1 if reset else 0), "multi stats")
+        return {"steps": int(st.steps), "records_received": int(st.records_received), "tiles_covered": int(st.tiles_covered),
+                "bytes_received": int(st.bytes_received),
+                "transport": {0: "auto", 1: "rccl", 2: "copy"}[int(st.transport)],
+                "gather": {0: "sparse", 1: "dense"}[int(st.gather)],
+                "rccl_version": int(st.rccl_version), "comm_ranks": int(st.comm_ranks)}
+
+    def comm_selftest(self, nbytes: int = 1 << 20):
+        check(lib.kifs_multi_comm_selftest(self._m, int(nbytes)), "multi comm_selftest")
 
     def set_weights(self, weights=None):
         """Shares of the devices (one integer each, None = equal)."""

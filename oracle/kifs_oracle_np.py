@@ -1,9 +1,14 @@
 """Second, independent restatement of the reference shader in NumPy float32.
 
 TEST INFRASTRUCTURE ONLY.  Written straight from the WGSL (entry.wgsl, julia.wgsl,
-kifs.wgsl, quaternions.wgsl), vectorised over the frame with masks, using NumPy's own
-sqrt/log and NO fused multiply-adds -- i.e. a different but equally legal evaluation of
-the same shader (WGSL leaves contraction and builtin precision to the implementation).
+gen_julia.wgsl, kifs.wgsl, quaternions.wgsl), vectorised over the frame with masks, using
+NumPy's own sqrt / log / log2 / power / arccos / sin / cos, true divisions everywhere and NO
+fused multiply-adds -- i.e. a different but equally legal evaluation of the same shader (WGSL
+leaves contraction and builtin precision to the implementation).  In particular it keeps the
+LITERAL form of everything the C oracle's arithmetic contract rewrote: `dot(n, p) / length(n)`
+in the mirror, and in quat_pow (quaternions.wgsl:57-63) two separate lengths, `real / norm`,
+`normalize(ijk)` and `pow(norm, x)`, with gen_julia.wgsl:16's `pow(q_sq_norm, power - 1)` taken
+on its own -- no shared log2, no reciprocals.
 Its job is to catch transcription errors in the C oracle (a wrong sign, a swapped
 column): the two must agree on almost every pixel, differing only where a 1-ulp change
 flips a `distance < epsilon` decision.  It is not bit-compatible with the C oracle or
@@ -52,6 +57,7 @@ class Scene:
         self.is_heatmap = bool(options.is_heatmap)
         self.group = int(options.fractal_group_id)
         self.primitive = int(options.primitive_id)
+        self.power = F(options.power)
         self.c = [F(options.constant[i]) for i in range(4)]
         self.sdf_iters, self.normal_iters, self.fold_iters = (
             int(iters.sdf_iters), int(iters.normal_iters), int(iters.fold_iters))
@@ -65,6 +71,64 @@ def quat_sq(q):
 
 def quat_add(a, b):
     return [x + y for x, y in zip(a, b)]
+
+
+def quat_pow(q, x):
+    """quaternions.wgsl:57-63, literally: norm = length(q); phi = acos(real / norm);
+    n = normalize(ijk); pow(norm, x) * (cos(x phi), n sin(x phi))."""
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        norm = _length(q)                       # quat_norm2, :18-20
+        phi = np.arccos(q[0] / norm).astype(F)
+        n = _normalize(q[1:])
+        pw = np.power(norm, x).astype(F)
+        a = x * phi
+        cs, sn = np.cos(a).astype(F), np.sin(a).astype(F)
+        return [pw * cs] + [pw * (c * sn) for c in n]
+
+
+# ---- gen_julia.wgsl ----------------------------------------------------------------------
+def genjulia_sdf(s, p):  # gen_julia.wgsl:5-27
+    norm = _length(p)
+    outside = norm > F(2.0) + s.epsilon
+    res = norm - F(2.0)
+    idx = np.nonzero(~outside)[0]
+    if idx.size:
+        q = [p[0][idx], p[1][idx], p[2][idx], np.full(idx.size, 0.1, dtype=F)]
+        qs = _dot(q, q)
+        dqs = np.ones(idx.size, dtype=F)
+        live = np.ones(idx.size, dtype=bool)
+        power = s.power
+        with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+            for _ in range(s.sdf_iters):
+                if not live.any():
+                    break
+                # :16  dq_sq_norm *= power * power * pow(q_sq_norm, power - 1)   (left to right)
+                factor = power * power * np.power(qs, power - F(1.0)).astype(F)
+                dqs = np.where(live, dqs * factor, dqs)
+                nq = quat_add(quat_pow(q, power), s.c)
+                q = [np.where(live, a, b) for a, b in zip(nq, q)]
+                qs = np.where(live, _dot(q, q), qs)
+                live = live & ~(qs > s.max_distance)
+            val = F(0.25) * np.log(qs) * np.sqrt(qs / dqs)
+        res = res.copy()
+        res[idx] = val.astype(F)
+    return res
+
+
+def genjulia_normal(s, p):  # gen_julia.wgsl:30-55
+    h, z = s.epsilon, F(0.0)
+    n = p[0].size
+    w = np.full(n, 0.1, dtype=F)
+    qs = []
+    for ax in range(3):
+        off = [h if i == ax else z for i in range(3)]
+        qs.append([pc + o for pc, o in zip(p, off)] + [w])
+        qs.append([pc - o for pc, o in zip(p, off)] + [w])
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        for _ in range(s.normal_iters):
+            qs = [quat_add(quat_pow(q, s.power), s.c) for q in qs]
+        l = [np.log2(_length(q)).astype(F) for q in qs]
+        return _normalize([l[0] - l[1], l[2] - l[3], l[4] - l[5]])
 
 
 # ---- julia.wgsl -----------------------------------------------------------------------
@@ -175,7 +239,76 @@ def kifs_sdf(s, p):
             scale = np.where(live, scale * F(2.0), scale)
             r = np.where(live, _length(pos), r)
         return (r - F(2.0)) / scale
+    if prim == 5:
+        return bunny_sdf(p)
     return np.ones(p[0].size, dtype=F)
+
+
+_BUNNY = None
+
+
+def _bunny_tables():
+    """The network's weights: DATA, read from the generated table the C oracle includes
+    (oracle/kifs_oracle_bunny.inc <- tools/gen_bunny_tables.py <- the literals of kifs.wgsl:90-136).
+    Only the numbers are shared; how they are combined below is this file's own reading."""
+    global _BUNNY
+    if _BUNNY is None:
+        import re
+        from pathlib import Path
+        text = (Path(__file__).resolve().parent / "kifs_oracle_bunny.inc").read_text()
+        tabs = {}
+        for name, body in re.findall(r"KOR_BUNNY_(\w+)(?:\[\d+\])+\s*=\s*\{(.*?)\};", text, flags=re.S):
+            vals = [float(v) for v in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?(?=f)", body)]
+            tabs[name] = np.array(vals, dtype=F)
+        _BUNNY = {"L0": tabs["L0"].reshape(4, 4, 4), "L1": tabs["L1"].reshape(4, 4, 4, 4),
+                  "L2": tabs["L2"].reshape(4, 4, 4, 4), "B1": tabs["B1"].reshape(4, 4),
+                  "B2": tabs["B2"].reshape(4, 4), "OUT": tabs["OUT"].reshape(4, 4)}
+    return _BUNNY
+
+
+def _mat_vec(m, v):
+    """Column-major mat4x4f (m[col][row]) times vec4 v: sum over columns of column * v[col], first
+    column first (no fma)."""
+    out = []
+    for r in range(4):
+        acc = m[0][r] * v[0]
+        for c in range(1, 4):
+            acc = acc + m[c][r] * v[c]
+        out.append(acc)
+    return out
+
+
+def bunny_sdf(p):  # kifs.wgsl:84-137
+    T = _bunny_tables()
+    d2 = _dot(p, p)
+    far = d2 > F(1.0)
+    res = (_length(p) - F(0.8)).astype(F)
+    idx = np.nonzero(~far)[0]
+    if idx.size:
+        # q = vec4(position.xzy * (-1, 1, -1), 1)
+        q = [p[0][idx] * F(-1.0), p[2][idx] * F(1.0), p[1][idx] * F(-1.0), np.ones(idx.size, dtype=F)]
+        f0 = [[np.sin(c).astype(F) for c in _mat_vec(T["L0"][u], q)] for u in range(4)]
+
+        def layer(W, bias, prev, scale):
+            out = []
+            for u in range(4):
+                acc = _mat_vec(W[u][0], prev[0])
+                for k in range(1, 4):
+                    acc = [a + b for a, b in zip(acc, _mat_vec(W[u][k], prev[k]))]
+                acc = [a + F(bias[u][r]) for r, a in enumerate(acc)]
+                sn = [np.sin(a).astype(F) for a in acc]
+                if scale is not None:
+                    sn = [v / scale for v in sn]            # `sin(...) / 1.4 + f1k`: a true division of the sine
+                out.append([v + prev[u][r] for r, v in enumerate(sn)])
+            return out
+        f1 = layer(T["L1"], T["B1"], f0, None)
+        f2 = layer(T["L2"], T["B2"], f1, F(1.4))
+        total = _dot(f2[0], [F(x) for x in T["OUT"][0]])
+        for u in range(1, 4):
+            total = total + _dot(f2[u], [F(x) for x in T["OUT"][u]])
+        res = res.copy()
+        res[idx] = (total - F(0.16)).astype(F)
+    return res
 
 
 def kifs_normal(s, p):
@@ -191,21 +324,23 @@ def kifs_normal(s, p):
 
 
 def scene_sdf(s, p):
-    return julia_sdf(s, p) if s.group == 1 else kifs_sdf(s, p)
+    return julia_sdf(s, p) if s.group == 1 else genjulia_sdf(s, p) if s.group == 2 else kifs_sdf(s, p)
 
 
 def scene_normal(s, p):
-    return julia_normal(s, p) if s.group == 1 else kifs_normal(s, p)
+    return julia_normal(s, p) if s.group == 1 else genjulia_normal(s, p) if s.group == 2 else kifs_normal(s, p)
 
 
 # ---- entry.wgsl -----------------------------------------------------------------------
-def render_linear(screen, camera, options, iters):
-    """Linear RGBA f32 (H, W, 4) and the loop counter i (H, W).  Julia and KIFS
-    primitives 0-4 only (no gen-Julia / bunny: those need the pinned transcendentals)."""
+def render_linear(screen, camera, options, iters, y0=0, y1=None):
+    """Linear RGBA f32 (H, W, 4) and the loop counter i (H, W).  Every pipeline: Julia, generalised
+    Julia, the KIFS primitives, Sierpinski and the bunny."""
     s = Scene(screen, camera, options, iters)
-    assert s.group in (0, 1) and not (s.group == 0 and s.primitive == 5)
-    W, H = s.width, s.height
-    ys, xs = np.mgrid[0:H, 0:W]
+    assert s.group in (0, 1, 2)
+    W = s.width
+    y1 = s.height if y1 is None else y1
+    H = y1 - y0  # rows of the band [y0, y1); pixel coordinates stay global
+    ys, xs = np.mgrid[y0:y1, 0:W]
     px = (xs.ravel().astype(F) + F(0.5))
     py = (ys.ravel().astype(F) + F(0.5))
     uvx = F(2.0) * px / s.h - s.aspect
@@ -258,8 +393,8 @@ def srgb_encode_ideal(x):
     return np.floor(v * 255.0 + 0.5).astype(np.uint8)
 
 
-def render(screen, camera, options, iters, encode=1):
-    lin, i, hit = render_linear(screen, camera, options, iters)
+def render(screen, camera, options, iters, encode=1, y0=0, y1=None):
+    lin, i, hit = render_linear(screen, camera, options, iters, y0, y1)
     if encode == 1:
         rgb = srgb_encode_ideal(lin[..., :3])
     else:

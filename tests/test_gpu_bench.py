@@ -46,10 +46,18 @@ def test_single_gpu_line_has_the_contract_fields():
     assert v["bound"] == "valu-issue" and 0.5 < v["frac_at_plain_rate"] < 1.0 and v["simds"] == 1024
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mpixels/s" and c["cores"] >= 1 and c["value"] > 0
+    assert d["settle_steps"] == cfg["settle_steps_before_warmup"] > 0
     sec = d["secondary"]
-    assert set(sec) == {"lone_frame", "orbit_x8", "fixed_camera"}
+    assert set(sec) == {"lone_frame", "orbit_x8", "fixed_camera", "cfg4_julia_4096", "ref_constants_1080p"}
     assert sec["lone_frame"]["frames_per_launch"] == 1 and sec["orbit_x8"]["frames_per_launch"] == 8
-    assert all(v["mpix_s"] > 0 and v["kernel_ms"] > 0 for v in sec.values())
+    assert all(sec[k]["mpix_s"] > 0 and sec[k]["kernel_ms"] > 0 for k in ("lone_frame", "orbit_x8", "fixed_camera"))
+    # the north star's 4096 x 4096 figure and the reference-constant run travel in the driver's own line
+    c4 = sec["cfg4_julia_4096"]
+    for form, frames in (("batched", 16), ("lone_frame", 1)):
+        assert c4[form]["width"] == c4[form]["height"] == 4096 and c4[form]["frames_per_launch"] == frames
+        assert c4[form]["mpix_s"] > 1000.0 and 0 < c4[form]["hbm_frac"] < 1 and c4[form]["kernel_ms"] > 0
+    ref = sec["ref_constants_1080p"]
+    assert ref["workload"] == "ref_julia_1080p" and ref["frames_per_launch"] == 48 and ref["mpix_s"] > 1000.0
     assert d["per_rank_kernel_ms"] == [pytest.approx(r["kernel_ms"], rel=1e-3)]
 
 
@@ -67,3 +75,44 @@ def test_two_ranks_are_started_by_bench_itself_and_gather_exact_frames():
     assert cfg["gather"] == "sparse" and 0.0 < cfg["tiles_sent_fraction"] < 0.2
     assert len(d["per_rank_kernel_ms"]) == 2 and all(x > 0 for x in d["per_rank_kernel_ms"])
     assert "frame_parallel" in d["secondary"] and "NOT the north star" in d["secondary"]["frame_parallel"]["note"]
+    comm = d["comm"]
+    assert comm["backend"].startswith("gloo") and comm["world_size_seen"] == 2 and comm["gather"] == "sparse"
+    assert comm["check"] is True
+
+
+def test_two_ranks_check_their_frames_by_default():
+    """Without --check: at N > 1 the last step's gathered frames are compared with single-GPU renders anyway."""
+    d = _run("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
+             "--frames-per-launch", "3", "--root-weight", "1", "--no-secondary", "--gather", "dense")
+    assert d["comm"]["check"] is True and d["gathered_frame_equals_single_gpu_frame"] is True
+    assert d["comm"]["gather"] == "dense" and d["comm"]["count_channel"] is None
+
+
+def test_one_process_drives_every_device_through_the_c_abi():
+    """--host one-process: no ranks, no torch.distributed -- kifs_multi_render_batch_async.  Three 'devices' on the
+    one GPU (peer-copy transport), frames checked against single-GPU renders; same JSON shape."""
+    d = _run("--gpus", "3", "--host", "one-process", "--share-device", "--steps", "6", "--warmup", "2",
+             "--frames-per-launch", "8")
+    assert d["n_gpus"] == 3 and d["scaling"] == "weak" and d["unit"] == "Mpixels/s"
+    cfg = d["config"]
+    assert cfg["frames_per_step"] == 24 and sum(cfg["rows_per_rank"]) == 1080 and "ONE process" in cfg["parallelism"]
+    comm = d["comm"]
+    assert comm["backend"] == "hip peer copies" and comm["check"] is True and comm["gather"] == "sparse"
+    assert 0.0 < comm["tiles_sent_fraction"] < 0.2 and comm["bytes_into_root_per_step"] > 0
+    assert d["gathered_frame_equals_single_gpu_frame"] is True
+    assert d["value"] > 1000.0 and len(d["per_rank_kernel_ms"]) == 3 and all(x > 0 for x in d["per_rank_kernel_ms"])
+    assert abs(d["value"] - 24 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["algorithmic_bytes_per_launch"] == 4 * 1920 * cfg["rows_per_rank"][0] * 24
+
+
+def test_whole_orbit_step():
+    """--whole-orbit: one step = all 120 poses, resident; reported with its launch count and total time."""
+    d = _run("--workload", "cfg3_sierpinski_1080p", "--whole-orbit", "--frames-per-launch", "48", "--steps", "3",
+             "--warmup", "1", "--cpu-seconds", "0", "--no-secondary")
+    cfg = d["config"]
+    assert cfg["frames_per_step"] == 120 and cfg["frames_per_launch"] == 48
+    wo = cfg["whole_orbit"]
+    assert wo["frames"] == 120 and wo["launches_per_step"] == 3 and wo["resident_bytes"] == 120 * 1920 * 1080 * 4
+    assert abs(wo["total_ms"] - d["ms_per_step"]) < 1e-3
+    assert abs(d["value"] - 120 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]

@@ -195,6 +195,34 @@ def test_shard_argument_checks(gs, kifs):
     gs.unpack_shard_async(frames, torch.ones((2, 24, 64, 4), dtype=torch.uint8, device="cuda:0"), [0, 2, 4])
     gs.synchronize()
     assert int(frames.sum()) == 2 * 24 * 64 * 4
+    # ... and the render: packed shard tensors are too small for in_place, which writes up to frame row H - 1
+    packed = torch.zeros((2, 24, 64, 4), dtype=torch.uint8, device="cuda:0")
+    two = [kifs.CameraData(), kifs.CameraData(phi=1.0)]
+    with pytest.raises(ValueError):
+        gs.render_shard_async([packed[0], packed[1]], two, [0, 2, 4], in_place=True)
+    with pytest.raises(ValueError):
+        gs.render_shard_async(kifs.DevicePointers([packed[0], packed[1]]), two, [0, 1, 2, 4])  # 32 rows needed
+    with pytest.raises(ValueError):
+        gs.render_shard_async([packed[0], packed[1]], two, [0, 5])  # stripe 5 is outside the 40-row frame
+    prepared = kifs.DevicePointers([packed[0], packed[1]])
+    gs.render_shard_async(prepared, two, [0, 2, 4])
+    gs.render_shard_async(prepared, two, [0, 2, 4])  # (checked once, remembered)
+    gs.synchronize()
+    # A stripe list is validated against the CURRENT frame height even when its device table is cached: a list
+    # accepted for a 2160-row frame must be refused once kifs_set_screen made the frame 1080 rows.
+    tall = [0, 100, 200, 269]
+    gs.update_screen_data(kifs.ScreenData(64, 2160))
+    big = torch.zeros((1, 32, 64, 4), dtype=torch.uint8, device="cuda:0")
+    gs.render_shard_async([big[0]], [kifs.CameraData()], tall)
+    gs.synchronize()
+    gs.update_screen_data(kifs.ScreenData(64, 1080))
+    st = arr(*tall)
+    one = (C.c_void_p * 1)(big.data_ptr())
+    assert lib.kifs_render_shard_async(gs._ctx, None, 1, None, one, 256, st, 4, 0, 1) == 7
+    assert lib.kifs_unpack_shard_async(gs._ctx, None, 1, out.data_ptr(), 256, 1080 * 256, big.data_ptr(), 256, 32 * 256, st, 4) == 7
+    assert lib.kifs_fill_shard_async(gs._ctx, None, 1, out.data_ptr(), 256, 1080 * 256, st, 4, 1) == 7
+    assert lib.kifs_render_shard_async(gs._ctx, None, 1, None, one, 256, arr(0, 100), 2, 0, 1) == 0
+    gs.synchronize()
 
 
 def test_shardframes_on_gpu_world1(gs, kifs, oracle):

@@ -14,9 +14,10 @@ renders BASELINE-sized frames with both and reports, per workload,
   max_nonflip   largest channel difference among pixels with the same hit/miss decision
 
 That is the envelope to expect against any real driver; the HIP kernels are held to the C
-oracle bit for bit.  CPU only (build container); writes profiles/r02/parity_envelope.json.
+oracle bit for bit.  CPU only (build container); writes profiles/<round>/parity_envelope.json.
+The NumPy side renders big frames in bands of rows (memory), the C oracle whole frames.
 
-    python tools/parity_envelope.py [workload ...]
+    python tools/parity_envelope.py [--round r03] [workload ...]
 """
 import json
 import sys
@@ -33,11 +34,32 @@ from oracle import kifs_oracle_np as NP  # noqa: E402
 import kifs_raymarching_amd as K  # noqa: E402  (host packing only: no GPU call is made)
 from kifs_raymarching_amd.configs import WORKLOADS  # noqa: E402
 
-DEFAULT = ["cfg2_julia_1080p", "cfg3_sierpinski_1080p", "ref_julia_1080p"]
+DEFAULT = ["cfg2_julia_1080p", "cfg3_sierpinski_1080p", "ref_julia_1080p", "cfg1_julia_256", "n1_genjulia_1080p",
+           "n1_genjulia_1080p_heatmap", "n1_genjulia_p3_1080p", "n1_genjulia_p8_n3_1080p",
+           "n2_bunny_1080p", "cfg4_julia_4096", "cfg5_sierpinski_8k_orbit"]
+BAND_ROWS = 256
+
+
+def _variants():
+    """Envelope-only views of the generalised Julia set.  With the reference's constants (power 8, ten normal
+    iterations WITHOUT an escape test, gen_julia.wgsl:41-48) every orbit of the six offset points overflows, the
+    normal is inf - inf = NaN and the hit pixel is black in BOTH readings -- so the as-shipped workload says nothing
+    about the orbit arithmetic.  These do: the march alone (heatmap), a power whose normals stay finite, and power 8
+    with three normal iterations."""
+    import dataclasses
+    base = WORKLOADS["n1_genjulia_1080p"]
+    gui = lambda **kw: dataclasses.replace(base.gui, **kw)
+    return {
+        "n1_genjulia_1080p_heatmap": dataclasses.replace(base, name=base.name + ", heatmap", gui=gui(is_heatmap=True)),
+        "n1_genjulia_p3_1080p": dataclasses.replace(base, name="1920x1080 generalised Julia, power 3, reference constants (100/10)",
+                                                    gui=gui(power=3.0)),
+        "n1_genjulia_p8_n3_1080p": dataclasses.replace(base, name="1920x1080 generalised Julia, power 8, 100 SDF / 3 normal iterations",
+                                                       iters=(100, 3, 10)),
+    }
 
 
 def envelope(key):
-    w = WORKLOADS[key]
+    w = WORKLOADS.get(key) or _variants()[key]
     ub = K.uniform_bytes
     s = O.from_bytes(O.Screen, ub(w.screen.into_buffer_data()))
     c = O.from_bytes(O.Camera, ub(w.camera.into_buffer_data()))
@@ -46,7 +68,12 @@ def envelope(key):
     t0 = time.perf_counter()
     a = O.render(s, c, o, it)
     t1 = time.perf_counter()
-    b, _, hit_np = NP.render(s, c, o, it)
+    _, steps_c, _ = O.render_stats(s, c, o, it)
+    H = w.screen.height
+    parts = [NP.render(s, c, o, it, y0=y, y1=min(H, y + BAND_ROWS)) for y in range(0, H, BAND_ROWS)]
+    b = np.concatenate([p[0] for p in parts], axis=0)
+    hit_np = np.concatenate([p[2] for p in parts], axis=0)
+    steps_np = np.concatenate([p[1] for p in parts], axis=0)
     t2 = time.perf_counter()
     bg = a[0, 0].copy()  # the corner is background in every BASELINE view
     hit_c = (a != bg).any(-1)
@@ -62,15 +89,22 @@ def envelope(key):
         "max_nonflip": int(d[~flip].max()) if (~flip).any() else 0,
         "nonflip_differ_pixels": int(((d > 0) & ~flip).sum()),
         "max_any": int(d.max()),
+        # the march itself, whatever the shading makes of it: per-pixel loop counters of entry.wgsl:12-25
+        "march_steps_differ_pixels": int((steps_c.astype(np.int64) != steps_np.astype(np.int64)).sum()),
         "c_oracle_s": round(t1 - t0, 1), "numpy_s": round(t2 - t1, 1),
     }
 
 
 def main():
-    keys = sys.argv[1:] or DEFAULT
-    out = ROOT / "profiles" / "r02" / "parity_envelope.json"
+    args = sys.argv[1:]
+    rnd = "r03"
+    if args[:1] == ["--round"]:
+        rnd, args = args[1], args[2:]
+    keys = args or DEFAULT
+    out = ROOT / "profiles" / rnd / "parity_envelope.json"
     out.parent.mkdir(parents=True, exist_ok=True)
-    res = []
+    res = json.loads(out.read_text()) if (out.exists() and args) else []  # named workloads: add to the file
+    res = [r for r in res if r["workload"] not in keys]
     for k in keys:
         r = envelope(k)
         print(json.dumps(r), flush=True)
