@@ -643,6 +643,16 @@ def main():
 
         if frames_per_step <= K.MAX_BATCH:
             sf.wrap_targets = K.DevicePointers  # a slot's destination pointers, collected once
+        if rank == 0:
+            # The hand-off of a step's gathered frames is part of the timed pipeline: a consumer stream takes them when
+            # they are complete (a no-op consumer: it waits for the frames and is done), and the slot's next fill and
+            # render are ordered after it.
+            def hand_off(k, frames):
+                consumer_stream.wait_stream(torch.cuda.current_stream())
+                done = torch.cuda.Event()
+                done.record(consumer_stream)
+                return done
+            sf.on_frames = hand_off
 
         def step(k):
             with torch.cuda.stream(streams[0]):
@@ -700,6 +710,7 @@ def main():
     # ---- the headline sequence
     sharded = world > 1 and args.shard in ("stripes", "bands")
     count_group = fill_stream = None
+    consumer_stream = torch.cuda.Stream(device=device) if sharded else None
     if sharded and args.gather == "sparse":
         # message sizes travel between the hosts over a CPU group, beside the RCCL transfers
         if args.backend == "nccl":

@@ -1,15 +1,26 @@
-"""Multi-GPU sharding of the render path: load-balanced row shards of batches of frames
-(ShardFrames, the default of bench.py at N > 1), contiguous row bands of one frame (BandFrame) or
-whole frames of a sequence (FrameStream), all delivered to a root rank by grouped point-to-point
-RCCL.
+"""Multi-GPU sharding of the render path, one process per GPU over torch.distributed: load-balanced row
+shards of batches of frames with a sparse gather (SparseShardFrames: the default of bench.py at N > 1) or a
+dense one (ShardFrames), contiguous row bands of one frame (BandFrame), or whole frames of a sequence
+(FrameStream), all delivered to a root rank by grouped point-to-point RCCL.  (One process driving all the
+devices uses the library's own kifs_multi_render_batch_async instead: graphics.MultiGraphicState.)
 
-Which one to use.  A frame's run time is the critical path of its longest rays (hundreds of
-dependent march steps), and every row band of the fractal still contains such rays, so bands
-barely shorten a frame: they are the low-LATENCY option.  THROUGHPUT scales over frames --
-the frames of an orbit are independent -- so FrameStream gives each rank whole frames and
-streams the finished ones to the root; that is the default of bench.py at N > 1.
+Which one to use.  THROUGHPUT comes from batches: every rank renders its 8-row stripes of all the step's
+frames in ONE launch (the expensive rows sit in the middle of the frame, so stripes are dealt round-robin
+rather than cut into contiguous bands) and rank 0 gathers them -- SparseShardFrames sends only the tiles
+that hold something, which is what keeps the root's one xGMI link per peer from being the bound.  A lone
+frame's run time is the critical path of its longest rays (hundreds of dependent march steps), and every
+row band of the fractal still contains such rays, so BandFrame barely shortens a frame: it is the
+low-LATENCY form.  FrameStream gives each rank whole frames and (optionally) streams the finished ones to
+the root: frame-parallel, no gathered frame -- bench.py reports it as a secondary figure only.
 
-Row-band sharding of one frame over the ranks of a node, gathered to a root rank.
+Hand-off of gathered frames (ShardFrames / SparseShardFrames).  frames(k) is complete and stable from the
+moment wait(k) returns until the slot is rendered into again, i.e. until step(k + buffers) starts; inside a
+step() loop that window is empty (step(k + buffers) itself calls wait(k) and then overwrites).  A consumer
+therefore registers `on_frames(k, frames)`: it is called from wait(k) right after the last stripe / record has
+been enqueued on the current stream, BEFORE the slot is reused, and may return an event (recorded on whatever
+stream the consumer reads the frames with); the slot's next fill and render are ordered after that event.
+
+BandFrame: row-band sharding of one frame over the ranks of a node, gathered to a root rank.
 
 Pixels are independent (entry.wgsl:49-59 reads only uniforms and its own position), so
 the frame shards by contiguous row bands: rank r renders rows kifs_band_range(H, r, N)
@@ -278,6 +289,9 @@ class ShardFrames:
             self._mine = [torch.zeros(shape(rank), dtype=torch.uint8, device=self.device) for _ in range(buffers)]
         self._works: List[Optional[list]] = [None] * buffers
         self._targets = [None] * buffers
+        self._step_of_slot = [None] * buffers  # which step's frames a slot holds (for on_frames)
+        self._consumed = [None] * buffers      # event returned by on_frames: the slot may be overwritten after it
+        self.on_frames: Optional[Callable] = None  # on_frames(k, frames) -> optional event (see the module docstring)
         self.wrap_targets = lambda outs: outs  # e.g. graphics.DevicePointers: the pointers collected once per slot
         self._staged = (world > 1 and self.device.type == "cuda"
                         and dist.get_backend(group) == "gloo")  # rehearsal on one GPU, see BandFrame
@@ -347,6 +361,23 @@ class ShardFrames:
                             self._recv[slot][r].copy_(self._host[slot][r])
                         self.unpack(self._frames[slot], self._recv[slot][r], self.stripes[r])
         self._works[slot] = None
+        self._hand_off(slot)
+
+    def _hand_off(self, slot: int):
+        """Root: the slot's frames are complete on the current stream -- give them to the consumer, once."""
+        k = self._step_of_slot[slot]
+        if k is None or self.rank != self.root:
+            return
+        self._step_of_slot[slot] = None
+        if self.on_frames is not None:
+            self._consumed[slot] = self.on_frames(k, self._frames[slot])
+
+    def _before_overwrite(self, slot: int):
+        """Order the current stream after the consumer of the slot's previous frames."""
+        ev = self._consumed[slot]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._consumed[slot] = None
 
     def wait_all(self):
         for slot in range(self.buffers):
@@ -356,9 +387,11 @@ class ShardFrames:
         """`render_shard(outs, first_frame, stripes, in_place)` renders this rank's stripes of the
         step's frames (sequence indices first_frame .. + count - 1)."""
         self.wait(k)
+        self._before_overwrite(k % self.buffers)
         if self.rows[self.rank] > 0:
             outs, in_place = self.targets(k)
             render_shard(outs, k * self.count, self.my_stripes, in_place)
+        self._step_of_slot[k % self.buffers] = k
         self.gather_async(k)
 
 
@@ -497,10 +530,14 @@ class SparseShardFrames(ShardFrames):
                 self._filled[slot] = True
         if self.fill_stream is not None:
             self.fill_stream.wait_event(self._slot_free[slot] or torch.cuda.current_stream().record_event())
+            if self._consumed[slot] is not None:  # the consumer of the slot's previous frames reads them until here
+                self.fill_stream.wait_event(self._consumed[slot])
             with torch.cuda.stream(self.fill_stream):
                 background()
                 self._fill_done[slot] = self.fill_stream.record_event()
         else:
+            if self._consumed[slot] is not None:
+                torch.cuda.current_stream().wait_event(self._consumed[slot])
             background()
 
     def _pack(self, k: int):
@@ -581,6 +618,8 @@ class SparseShardFrames(ShardFrames):
                 if self.fill_stream is not None:
                     self._slot_free[slot] = torch.cuda.current_stream().record_event()
         self._works[slot] = None
+        if works is not None:
+            self._hand_off(slot)
 
     def wait_all(self):
         if self._unflushed is not None:
@@ -592,9 +631,11 @@ class SparseShardFrames(ShardFrames):
     def step(self, k: int, render_shard: Callable):
         self.wait(k)
         self._start_fill(k)
+        self._before_overwrite(k % self.buffers)  # (after _start_fill, which orders the fill stream after it too)
         if self.rows[self.rank] > 0:
             outs, in_place = self.targets(k)
             render_shard(outs, k * self.count, self.my_stripes, in_place)
+        self._step_of_slot[k % self.buffers] = k
         self._pack(k)
         if self._unflushed is not None:  # step k - 1: its count has had a whole step to reach the host
             self._flush(self._unflushed)

@@ -201,7 +201,7 @@ def _oracle_rows(O, sc, cam, opt, it, height, stripes):
 
 
 def _shard_worker(rank, world, port, width, height, steps, count, weights, contiguous, outdir, sparse=False,
-                  distance=3.0):
+                  distance=3.0, hook=False):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -250,21 +250,56 @@ def _shard_worker(rank, world, port, width, height, steps, count, weights, conti
                     out.copy_(rows)
 
         got = []
-        for k in range(steps):
-            sf.step(k, render_shard)
-            if k >= 1:
-                sf.wait(k - 1)
-                if rank == 0:
-                    got.append(sf.frames(k - 1).clone().numpy())
-        sf.wait_all()
+        if hook:
+            # a plain step() loop (what bench.py times): the consumer is handed every step's frames exactly once,
+            # complete, before their slot is rendered into again
+            handed = {}
+
+            def on_frames(k, frames):
+                assert k not in handed
+                handed[k] = frames.clone().numpy()
+            sf.on_frames = on_frames
+            for k in range(steps):
+                sf.step(k, render_shard)
+                assert sorted(handed) == list(range(max(0, k - 1))) or rank != 0  # two buffers: step k hands off k - 2
+            sf.wait_all()
+            got = [handed[k] for k in range(steps)] if rank == 0 else []
+        else:
+            for k in range(steps):
+                sf.step(k, render_shard)
+                if k >= 1:
+                    sf.wait(k - 1)
+                    if rank == 0:
+                        got.append(sf.frames(k - 1).clone().numpy())
+            sf.wait_all()
+            if rank == 0:
+                got.append(sf.frames(steps - 1).clone().numpy())
         if rank == 0:
-            got.append(sf.frames(steps - 1).clone().numpy())
             np.save(os.path.join(outdir, "shards.npy"), np.concatenate(got, axis=0))
             if sparse:
                 np.save(os.path.join(outdir, "sparse_stats.npy"), np.array([sf.records_sent, sf.tiles_seen]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height,count,weights,contiguous,sparse,width,distance,hook", [
+    (2, 40, 2, None, False, False, 40, 3.0, True),  # frames handed to a consumer from a plain step() loop: dense
+    (3, 43, 2, None, False, True, 72, 3.0, True),   # ... and sparse (the slot's erase follows the hand-off)
+])
+def test_shard_frames_are_handed_to_a_consumer_before_their_slot_is_reused(world, height, count, weights, contiguous, sparse,
+                                                                           width, distance, hook, tmp_path, oracle):
+    steps = 6
+    mp.spawn(_shard_worker,
+             args=(world, _free_port(), width, height, steps, count, weights, contiguous, str(tmp_path), sparse, distance, hook),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "shards.npy")
+    assert got.shape == (steps * count, height, width, 4)
+    sc = oracle.screen_uniform(width, height)
+    opt = oracle.options_from_gui(fractal_group=1, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=40)
+    for f in range(steps * count):
+        want = oracle.render(sc, oracle.camera_uniform(distance, 0.3 * f, 0.1), opt, oracle.iters(8, 4, 4))
+        assert (got[f] == want).all(), f"frame {f} differs"
 
 
 @pytest.mark.parametrize("world,height,count,weights,contiguous,sparse,width,distance", [
