@@ -186,6 +186,15 @@ def _load():
             f"{LIB_PATH} is missing: the HIP library has not been built "
             "(run __graft_entry__.build() or make -C kifs_raymarching_amd/csrc). "
             "There is no CPU fallback.")
+    # a library older than its sources (edited, not rebuilt) is refused, not used: measurements and parity
+    # claims must belong to the code in the tree
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_kifs_build_check", PKG_DIR / "build.py")
+    kb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kb)
+    if kb.STAMP.exists() and not kb.is_current():
+        raise ImportError(f"{LIB_PATH} was built from other sources than the ones in csrc/ (hash mismatch): rebuild it "
+                          "(python -c 'import __graft_entry__ as g; g.build()')")
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -263,7 +263,8 @@ def test_product_srgb_table_matches_oracle(oracle, kifs):
 
 
 # ---- independent restatement ------------------------------------------------------------
-@pytest.mark.parametrize("case", ["julia", "julia_ref", "sierpinski", "torus", "heatmap"])
+@pytest.mark.parametrize("case", ["julia", "julia_ref", "sierpinski", "torus", "heatmap", "genjulia_p8", "genjulia_p3",
+                                  "genjulia_p2", "genjulia_p8_n3", "bunny", "bunny_close"])
 def test_c_oracle_agrees_with_numpy_restatement(oracle, case):
     """Two independent readings of the WGSL (C with pinned op order vs NumPy with libm and
     no fma) must agree except where a 1-ulp difference flips `distance < epsilon`."""
@@ -278,6 +279,17 @@ def test_c_oracle_agrees_with_numpy_restatement(oracle, case):
                                                                fractal_color=(250, 120, 60)), oracle.iters()),
         "heatmap": (oracle.camera_uniform(3.0), _opts(oracle, fractal_group=1, is_heatmap=True,
                                                       constant=(-0.2, 0.6, 0.2, 0.2)), oracle.iters(12, 10, 10)),
+        # N1 / N2: the NumPy side reads quat_pow (quaternions.wgsl:57-63), gen_julia.wgsl:16 and the bunny network
+        # (kifs.wgsl:84-137) LITERALLY -- two lengths, true divisions, pow, separate log2 -- against the C oracle's
+        # contract form (shared log2, reciprocal products, pinned polynomials)
+        "genjulia_p8": (oracle.camera_uniform(3.0, 0.5, 0.3), _opts(oracle, fractal_group=2, power=8.0), oracle.iters()),
+        "genjulia_p3": (oracle.camera_uniform(3.0, 1.5, -0.3), _opts(oracle, fractal_group=2, power=3.0, max_iterations=128),
+                        oracle.iters(40, 10, 10)),
+        "genjulia_p2": (oracle.camera_uniform(3.0), _opts(oracle, fractal_group=2, power=2.0, constant=(-0.2, 0.6, 0.2, 0.2),
+                                                           max_iterations=64), oracle.iters(12, 10, 10)),
+        "genjulia_p8_n3": (oracle.camera_uniform(2.6, 2.0, 0.1), _opts(oracle, fractal_group=2, power=8.0), oracle.iters(100, 3, 10)),
+        "bunny": (oracle.camera_uniform(2.2, 0.8, 0.2), _opts(oracle, primitive_shape=5), oracle.iters()),
+        "bunny_close": (oracle.camera_uniform(1.6, 3.8, -0.4), _opts(oracle, primitive_shape=5), oracle.iters()),
     }[case]
     cam, o, it = cfg
     a = oracle.render(sc, cam, o, it)

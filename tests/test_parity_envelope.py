@@ -1,0 +1,40 @@
+"""The parity envelope, pinned: how far the C oracle (the arithmetic contract the kernels are held to bit for bit) is
+from the LITERAL NumPy reading of the WGSL at BASELINE size, against the figures recorded under
+profiles/r03/parity_envelope.json (tools/parity_envelope.py).  The reference shader cannot be run here ("parity
+unpinned"); this is the guard that a change of the contract cannot silently widen the distance
+to the literal shader: whoever touches oracle/kifs_oracle.c re-runs the tool, and this test fails if the pixels that
+differ, the pixels beyond the north star's +-1, or the hit/miss flips grew.  CPU only; ~25 s."""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+RECORDED = {r["workload"]: r for r in json.loads((ROOT / "profiles" / "r03" / "parity_envelope.json").read_text())}
+
+
+@pytest.mark.parametrize("key", ["cfg2_julia_1080p", "ref_julia_1080p", "n2_bunny_1080p", "n1_genjulia_p3_1080p"])
+def test_envelope_does_not_exceed_the_recorded_one(key, oracle, kifs):
+    sys.path.insert(0, str(ROOT / "tools"))
+    import parity_envelope as PE
+    got = PE.envelope(key)
+    want = RECORDED[key]
+    assert got["pixels"] == want["pixels"] == 1920 * 1080
+    # the same toolchain reproduces the recorded figures exactly; another libm may move a few pixels
+    slack = lambda n: n + max(3, n // 10)
+    for field in ("differ_pixels", "differ_gt1_pixels", "flip_pixels", "march_steps_differ_pixels"):
+        assert got[field] <= slack(want[field]), (key, field, got[field], want[field])
+    assert got["max_nonflip"] <= max(want["max_nonflip"], 1) + 8
+    # and the north star's tolerance holds for all but a few pixels in a hundred thousand
+    assert got["differ_gt1_pixels"] / got["pixels"] < 5e-5
+
+
+def test_recorded_envelope_covers_every_pipeline():
+    for key in ("cfg1_julia_256", "cfg2_julia_1080p", "cfg3_sierpinski_1080p", "cfg4_julia_4096", "cfg5_sierpinski_8k_orbit",
+                "ref_julia_1080p", "n1_genjulia_1080p", "n1_genjulia_1080p_heatmap", "n1_genjulia_p3_1080p",
+                "n1_genjulia_p8_n3_1080p", "n2_bunny_1080p"):
+        assert key in RECORDED, key
+        r = RECORDED[key]
+        assert r["differ_gt1_pixels"] <= r["differ_pixels"] <= r["pixels"]

@@ -20,6 +20,10 @@ done
 for w in cfg5_sierpinski_8k_orbit cfg5_sierpinski_8k_orbit_shadows; do
   python bench.py --workload $w --steps 40 --warmup 6 --cpu-seconds 0 --no-secondary --frames-per-launch 1 >> $O/other_workloads_bench.jsonl
   python bench.py --workload $w --steps 12 --warmup 3 --cpu-seconds 0 --no-secondary --frames-per-launch 4 >> $O/other_workloads_bench.jsonl
+  # the workload as BASELINE.json names it: the WHOLE 120-frame orbit, every frame resident (15.9 GB), per launch size
+  for b in 4 8 16 24; do
+    python bench.py --workload $w --whole-orbit --steps 3 --warmup 1 --cpu-seconds 0 --no-secondary --frames-per-launch $b >> $O/other_workloads_bench.jsonl
+  done
   echo "bench $w done"
 done
 cd /tmp && export TMPDIR=/tmp
