@@ -447,10 +447,15 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
 template <int GROUP, int PRIM>
 __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     constexpr uint32_t CAP = TILE_W * TILE_H;  // every pixel of the tile could be a live ray
-    __shared__ float s_srgb[256];
-    __shared__ uint32_t s_tile[TILE_H][TILE_W];
     __shared__ uint32_t q_pix[2][CAP];  // ly << 5 | lx
     __shared__ float q_t[2][CAP];
+    // The ray direction of every live pixel, computed once at set-up: fs_main's two divisions by the height, a
+    // square root and normalize()'s three divisions are ~90 of the ~160 instructions a chunk pays per round outside
+    // the march itself.  3 KB -- paid for by the staging tile and the sRGB table, which are needed only once the
+    // march is over and live in queue buffer 0 by then (the hit list is in buffer 1): 7 KB per wave instead of 6.
+    __shared__ float s_dir[3][CAP];
+    uint32_t (*const s_tile)[TILE_W] = reinterpret_cast<uint32_t (*)[TILE_W]>(&q_pix[0][0]);
+    float* const s_srgb = &q_t[0][0];
     // The hit list grows down from the top of buffer 1 (hit i at index CAP - 1 - i).  Every pixel is a live
     // ray, a hit or finished, so (rays at the start of a round) + (hits before it) <= CAP.  When buffer 1
     // receives the next round's queue (growing up from 0) the two cannot meet.  When buffer 1 holds THIS
@@ -496,8 +501,12 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
         if (alive) {
             const uint32_t i = n + uint32_t(__builtin_popcountll(m & below));
-            q_pix[0][i] = (uint32_t(ly) << 5) | uint32_t(lx);
+            const uint32_t pix = (uint32_t(ly) << 5) | uint32_t(lx);
+            q_pix[0][i] = pix;
             q_t[0][i] = 0.0f;
+            s_dir[0][pix] = dir.x;
+            s_dir[1][pix] = dir.y;
+            s_dir[2][pix] = dir.z;
         }
         n += uint32_t(__builtin_popcountll(m));
     }
@@ -517,12 +526,6 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
         }
         return;
     }
-    if (srgb) {
-#pragma unroll
-        for (uint32_t i = 0; i < 256; i += 64) s_srgb[i + lane] = P.srgb_table[i + lane];
-    }
-#pragma unroll
-    for (int r = 0; r < TILE_H; r += 2) s_tile[r + int(lane >> 5)][lane & 31u] = P.background_rgba;
     __syncthreads();  // one wave: orders the LDS traffic, costs nothing
 
     // ---- rounds
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
             if (have) {
                 pix = q_pix[cur][c0 + lane];
                 t = q_t[cur][c0 + lane];
-                dir = ray_direction(P, tile_x + int(pix & 31u), frame_y + int(pix >> 5));
+                dir = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
             }
             // a ray that has advanced has t > 0 (epsilon > 0 on this path) and sits at fma(t, dir, origin)
             V3 p = (trips == 0) ? P.origin
@@ -572,13 +575,22 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
         __syncthreads();
     }
 
+    // ---- the march is over: queue buffer 0 becomes the staging tile (background) and the sRGB table
+    if (srgb) {
+#pragma unroll
+        for (uint32_t i = 0; i < 256; i += 64) s_srgb[i + lane] = P.srgb_table[i + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < TILE_H; r += 2) s_tile[r + int(lane >> 5)][lane & 31u] = P.background_rgba;
+    __syncthreads();
+
     // ---- shade the hits, 64 at a time
     for (uint32_t i0 = 0; i0 < hits; i0 += 64u) {
         if (i0 + lane < hits) {
             const uint32_t pix = q_pix[1][CAP - 1u - (i0 + lane)];
             const float t = q_t[1][CAP - 1u - (i0 + lane)];
             const int hx = int(pix & 31u), hy = int(pix >> 5);
-            const V3 dir = ray_direction(P, tile_x + hx, frame_y + hy);
+            const V3 dir = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
             const V3 p = (t == 0.0f) ? P.origin
                                      : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
                                           fmaf_(t, dir.z, P.origin.z)};
