@@ -238,12 +238,12 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     __shared__ uint32_t s_tile[T][TILE_H][TILE_W];
     __shared__ uint32_t s_tiles[T];  // the group's tiles (x | y << 16), 0xffffffff past the table's end
     __shared__ int s_rows[T];        // first frame row of each of them
-    // queue entry: pixel (tile-in-group << 8 | ly << 5 | lx) and t; the direction is recomputed from the
-    // pixel every round (~55 instructions against the ~3400 of a round): 8 bytes per ray instead of 20 let
-    // seven workgroups share a CU instead of five, and it is resident workgroups -- each, for most of its
-    // life, one wave marching a thin tail of long rays -- that set a batched launch's rate
+    // queue entry: pixel (tile-in-group << 8 | ly << 5 | lx) and t: 8 bytes per ray; the ray's direction is
+    // computed once at set-up and looked up by pixel (fs_main's two divisions by the height, a square root and
+    // normalize()'s three divisions are ~90 instructions a ray would otherwise pay every round)
     __shared__ uint32_t q_pix[2][CAP];
     __shared__ float q_t[2][CAP];
+    __shared__ float s_dir[3][CAP];
     __shared__ uint32_t h_pix[CAP];  // hit list: pixel and t (the direction is recomputed)
     __shared__ float h_t[CAP];
     // three counters for two buffers: round r reads count[r % 3], appends under count[(r + 1) % 3] and
@@ -296,8 +296,12 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
         base = __builtin_amdgcn_readfirstlane(base);
         if (alive) {
             const uint32_t i = base + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
-            q_pix[0][i] = (uint32_t(j) << 8) | (uint32_t(ly) << 5) | uint32_t(lx);
+            const uint32_t pix = (uint32_t(j) << 8) | (uint32_t(ly) << 5) | uint32_t(lx);
+            q_pix[0][i] = pix;
             q_t[0][i] = 0.0f;
+            s_dir[0][pix] = dir.x;
+            s_dir[1][pix] = dir.y;
+            s_dir[2][pix] = dir.z;
         }
     }
     __syncthreads();
@@ -324,8 +328,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             if (have) {
                 pix = q_pix[cur][idx];
                 t = q_t[cur][idx];
-                const uint32_t tile = s_tiles[pix >> 8];
-                dir = ray_direction(P, int(tile & 0xffffu) * TILE_W + int(pix & 31u), s_rows[pix >> 8] + int((pix >> 5) & 7u));
+                dir = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
             }
             // a ray that has advanced has t > 0 (epsilon > 0 on this path), and then its position
             // is what the march last computed: fma(t, dir, origin)
@@ -380,9 +383,8 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
         if (i < hits) {
             const uint32_t pix = h_pix[i];
             const float t = h_t[i];
-            const uint32_t tile = s_tiles[pix >> 8];
             const int hx = int(pix & 31u), hy = int((pix >> 5) & 7u);
-            const V3 dir = ray_direction(P, int(tile & 0xffffu) * TILE_W + hx, s_rows[pix >> 8] + hy);
+            const V3 dir = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
             const V3 p = (t == 0.0f) ? P.origin
                                      : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
                                           fmaf_(t, dir.z, P.origin.z)};
