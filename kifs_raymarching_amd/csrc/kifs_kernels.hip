@@ -449,15 +449,16 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
 template <int GROUP, int PRIM>
 __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     constexpr uint32_t CAP = TILE_W * TILE_H;  // every pixel of the tile could be a live ray
-    __shared__ uint32_t q_pix[2][CAP];  // ly << 5 | lx
+    __shared__ uint8_t q_pix[2][CAP];  // ly << 5 | lx: a byte
     __shared__ float q_t[2][CAP];
     // The ray direction of every live pixel, computed once at set-up: fs_main's two divisions by the height, a
     // square root and normalize()'s three divisions are ~90 of the ~160 instructions a chunk pays per round outside
-    // the march itself.  3 KB -- paid for by the staging tile and the sRGB table, which are needed only once the
-    // march is over and live in queue buffer 0 by then (the hit list is in buffer 1): 7 KB per wave instead of 6.
+    // the march itself.  3 KB -- paid for by the pixel ids shrinking to bytes, the staging tile moving into queue
+    // buffer 0 once the march is over (the hit list is in buffer 1), and the sRGB thresholds read from memory (only
+    // hit pixels are encoded: 2 % of a frame): 5.5 KB per wave, and LDS must stay under 6.6 KB -- the 24 waves per CU
+    // the kernel's SGPRs allow are worth 7 % over 22 (KIFS_LDS_PAD sweep: 7 / 8 / 9 KB: 100.2 / 93.6 / 88.5 Gpixel/s).
     __shared__ float s_dir[3][CAP];
-    uint32_t (*const s_tile)[TILE_W] = reinterpret_cast<uint32_t (*)[TILE_W]>(&q_pix[0][0]);
-    float* const s_srgb = &q_t[0][0];
+    uint32_t (*const s_tile)[TILE_W] = reinterpret_cast<uint32_t (*)[TILE_W]>(&q_t[0][0]);
     // The hit list grows down from the top of buffer 1 (hit i at index CAP - 1 - i).  Every pixel is a live
     // ray, a hit or finished, so (rays at the start of a round) + (hits before it) <= CAP.  When buffer 1
     // receives the next round's queue (growing up from 0) the two cannot meet.  When buffer 1 holds THIS
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
         if (alive) {
             const uint32_t i = n + uint32_t(__builtin_popcountll(m & below));
             const uint32_t pix = (uint32_t(ly) << 5) | uint32_t(lx);
-            q_pix[0][i] = pix;
+            q_pix[0][i] = uint8_t(pix);
             q_t[0][i] = 0.0f;
             s_dir[0][pix] = dir.x;
             s_dir[1][pix] = dir.y;
@@ -561,11 +562,11 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
             const unsigned long long mq = __builtin_amdgcn_ballot_w64(marching);
             if (hit) {
                 const uint32_t i = CAP - 1u - (hits + uint32_t(__builtin_popcountll(mh & below)));
-                q_pix[1][i] = pix;
+                q_pix[1][i] = uint8_t(pix);
                 q_t[1][i] = t;
             } else if (marching) {
                 const uint32_t i = n_next + uint32_t(__builtin_popcountll(mq & below));
-                q_pix[cur ^ 1u][i] = pix;
+                q_pix[cur ^ 1u][i] = uint8_t(pix);
                 q_t[cur ^ 1u][i] = t;
             }
             hits += uint32_t(__builtin_popcountll(mh));
@@ -577,11 +578,8 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
         __syncthreads();
     }
 
-    // ---- the march is over: queue buffer 0 becomes the staging tile (background) and the sRGB table
-    if (srgb) {
-#pragma unroll
-        for (uint32_t i = 0; i < 256; i += 64) s_srgb[i + lane] = P.srgb_table[i + lane];
-    }
+    // ---- the march is over: queue buffer 0 becomes the staging tile (background)
+    const float* const s_srgb = P.srgb_table;  // (read from memory: see the LDS budget above)
 #pragma unroll
     for (int r = 0; r < TILE_H; r += 2) s_tile[r + int(lane >> 5)][lane & 31u] = P.background_rgba;
     __syncthreads();
