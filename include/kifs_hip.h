@@ -152,6 +152,10 @@ int kifs_set_extensions(kifs_ctx* ctx, const KifsExtensions* ext);
  * full frame).  Row y goes to out + (y - y0) * pitch_bytes, 4 bytes per pixel,
  * R G B A.  pitch_bytes >= 4*W and a multiple of 4.
  *
+ * The library launches on non-blocking streams (its own, or the caller's `hip_stream`): work the caller has
+ * pending on OTHER streams for the destination (a fill, a previous consumer) is not ordered before the render
+ * unless the caller orders it, as with any asynchronous HIP work.
+ *
  * kifs_render: `out` may be a device pointer of the context's device or a host
  * pointer; returns once `out` holds the pixels.
  * kifs_render_async: `out` must be device memory; the launch is enqueued on

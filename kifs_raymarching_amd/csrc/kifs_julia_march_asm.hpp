@@ -114,6 +114,40 @@
         "s_add_u32 %[nout], %[nout], 1\n"                    // diagnostics: steps with outside lanes
         "s_mov_b64 s[76:77], exec\n"
         "s_mov_b64 exec, s[78:79]\n"
+        // With the culls enabled (s[74:75] != 0: a sane scene, fill_params / enqueue_batch) n2 is a finite normal
+        // number here -- above bound_n2 >= 4, below (|origin| + max_distance)^2 < 4e30 -- so the correctly rounded
+        // square root needs neither the 2^32 pre-scaling (below 2^-96) nor the zero / infinity patch: the same
+        // v_sqrt and one-ulp fix-up on the same operand, eight instructions and two wait states shorter.  Every
+        // ray spends its first steps and, if it misses, its last ones out here.
+        "s_cmp_lg_u64 s[74:75], 0\n"
+        "s_cbranch_scc0 48f\n"                                // culls off: the general form, out of line
+        "v_sqrt_f32_e32 v61, v52\n"
+        "s_nop 0\n"
+        "v_add_u32_e32 v62, -1, v61\n"                       // candidates one ulp either side
+        "v_add_u32_e32 v63, 1, v61\n"
+        "v_fma_f32 v55, -v62, v61, v52\n"
+        "v_fma_f32 v56, -v63, v61, v52\n"
+        "v_cmp_ge_f32_e64 s[80:81], 0, v55\n"
+        "v_cmp_lt_f32_e64 s[82:83], 0, v56\n"
+        "s_nop 0\n"
+        "v_cndmask_b32_e64 v62, v61, v62, s[80:81]\n"
+        "v_cndmask_b32_e64 v60, v62, v63, s[82:83]\n"
+        "49:\n"
+        "v_add_f32_e32 v54, -2.0, v60\n"                      // d = norm - 2
+        // early ray termination: outside the sphere with margin and heading away from it, the
+        // ray cannot come back inside, so it can never hit: retire the lane as a miss now
+        "v_mul_f32_e32 v55, v32, v35\n"                       // dot(p, dir)
+        "v_fma_f32 v55, v30, v36, v55\n"
+        "v_fma_f32 v55, v31, v37, v55\n"
+        "v_cmp_lt_f32_e32 vcc, %[cull], v52\n"                // n2 > 1.1 R^2 (never when cull = 0 -> see below)
+        "v_cmp_lt_f32_e64 s[80:81], 0, v55\n"                 // moving outwards
+        "s_and_b64 vcc, vcc, s[80:81]\n"
+        "s_and_b64 vcc, vcc, s[74:75]\n"                      // culling enabled?
+        "s_andn2_b64 s[76:77], s[76:77], vcc\n"               // drop them from the live lanes
+        "s_mov_b64 exec, s[76:77]\n"
+        "s_branch 41b\n"
+        // ---- the general square root of n2 (any operand), for scenes whose culls are off
+        "48:\n"
         "v_mul_f32_e32 v61, 0x4f800000, v52\n"
         "v_cmp_gt_f32_e32 vcc, 0x0f800000, v52\n"
         "s_nop 1\n"
@@ -134,19 +168,7 @@
         "v_cmp_class_f32_e64 vcc, v60, s94\n"
         "s_nop 1\n"
         "v_cndmask_b32_e32 v60, v61, v60, vcc\n"
-        "v_add_f32_e32 v54, -2.0, v60\n"                      // d = norm - 2
-        // early ray termination: outside the sphere with margin and heading away from it, the
-        // ray cannot come back inside, so it can never hit: retire the lane as a miss now
-        "v_mul_f32_e32 v55, v32, v35\n"                       // dot(p, dir)
-        "v_fma_f32 v55, v30, v36, v55\n"
-        "v_fma_f32 v55, v31, v37, v55\n"
-        "v_cmp_lt_f32_e32 vcc, %[cull], v52\n"                // n2 > 1.1 R^2 (never when cull = 0 -> see below)
-        "v_cmp_lt_f32_e64 s[80:81], 0, v55\n"                 // moving outwards
-        "s_and_b64 vcc, vcc, s[80:81]\n"
-        "s_and_b64 vcc, vcc, s[74:75]\n"                      // culling enabled?
-        "s_andn2_b64 s[76:77], s[76:77], vcc\n"               // drop them from the live lanes
-        "s_mov_b64 exec, s[76:77]\n"
-        "s_branch 41b\n"
+        "s_branch 49b\n"
         KIFS_JULIA_DIVSQRT_OUT_OF_LINE
         "19:\n"                                               // hand the current step to the general loop
         "s_or_b64 %[live], exec, s[78:79]\n"

@@ -161,7 +161,9 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
             }
         }
         const float R = B + o.epsilon;
-        const bool sane = B > 0.0f && R > 0.5f && R < 1.0e6f && o.epsilon >= 0.0f;
+        // (max_distance below 1e15 -- the GUI's range ends at 1e4 -- and, per view, an origin within 1e15 of the
+        // scene: enqueue_batch; the long-ray loop's square root of |p|^2 relies on |p|^2 being finite then)
+        const bool sane = B > 0.0f && R > 0.5f && R < 1.0e6f && o.epsilon >= 0.0f && o.max_distance < 1.0e15f;
         P->cull_n2 = sane ? 1.1f * R * R : 0.0f;
         // the wave-level quick exit uses a sphere 9 % larger again; like the culls, not in heatmap mode
         P->quick_cull_n2 = (sane && !o.is_heatmap && o.max_iterations > 0) ? 1.2f * R * R : 0.0f;
@@ -415,6 +417,7 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         if (c->views_busy[vs] && !hip_ok(hipEventSynchronize(c->views_used[vs]), "wait(view table)")) return KIFS_ERR_RUNTIME;
         c->views_busy[vs] = false;
     }
+    bool far_origin = false;  // a view whose origin is not within 1e15 of the scene: no culls for this launch
     for (int i = 0; i < count; ++i) {
         const KifsCameraUniform& cam = cameras ? cameras[i] : c->camera;
         kifs::BatchView& v = big ? c->h_views[vs][i] : B.view[i];
@@ -423,6 +426,8 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         v.m1 = {cam.matrix[1][0], cam.matrix[1][1], cam.matrix[1][2]};
         v.m2 = {cam.matrix[2][0], cam.matrix[2][1], cam.matrix[2][2]};
         v.out = reinterpret_cast<uint32_t*>(outs[i]);
+        if (!(double(v.origin.x) * v.origin.x + double(v.origin.y) * v.origin.y + double(v.origin.z) * v.origin.z < 1.0e30))
+            far_origin = true;  // (also NaN)
         if (P.tile_cull_beta > 0.0f) {  // the tile-level cull's angle bound assumes an orthonormal matrix
             const kifs::V3* m[3] = {&v.m0, &v.m1, &v.m2};
             for (int a = 0; a < 3; ++a)
@@ -431,6 +436,11 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
                     if (!(std::fabs(dot - (a == b ? 1.0 : 0.0)) <= 1.0e-3)) P.tile_cull_beta = 0.0f;
                 }
         }
+    }
+    if (far_origin) {
+        P.cull_n2 = 0.0f;
+        P.quick_cull_n2 = 0.0f;
+        P.tile_cull_beta = 0.0f;
     }
     const kifs::BatchView& view0 = big ? c->h_views[vs][0] : B.view[0];
     P.origin = view0.origin;

@@ -62,6 +62,43 @@ def test_frame_bit_exact(name, encode, gs, kifs, oracle):
         assert (want[..., :3] != want[0, 0, :3]).any()
 
 
+@pytest.mark.parametrize("what", ["huge_max_distance", "far_origin", "far_origin_batched"])
+def test_scenes_outside_the_cull_conditions(what, gs, kifs, oracle):
+    """The bounding-sphere culls -- and with them the short square root of the long-ray loop's outside-the-sphere
+    steps -- are on only for sane scenes: max_distance below 1e15 and every view's origin within 1e15 of the scene.
+    Beyond that the general forms run; frames must equal the oracle's either way (they are not empty: from 20 units
+    away the fractal is a few pixels, and a ray that overshoots by a rounding error of its huge t lands anywhere)."""
+    import torch
+    from kifs_raymarching_amd.configs import JULIA_C
+    screen = kifs.ScreenData(160, 96)
+    iters = (12, 10, 10)
+    if what == "huge_max_distance":
+        gui = kifs.GuiData(max_iterations=96, max_distance=3.0e16, fractal_group=kifs.FractalGroup.JuliaSet, constant=JULIA_C)
+        cams = [kifs.CameraData(origin_distance=20.0, phi=0.3)]
+    else:
+        gui = kifs.GuiData(max_iterations=96, max_distance=1.0e4, fractal_group=kifs.FractalGroup.JuliaSet, constant=JULIA_C)
+        cams = [kifs.CameraData(origin_distance=4.0e15, phi=0.3)]
+        if what == "far_origin_batched":  # one far view switches the culls off for the whole launch
+            cams = [kifs.CameraData(origin_distance=3.5, phi=0.3), kifs.CameraData(origin_distance=4.0e15, phi=0.3),
+                    kifs.CameraData(origin_distance=5.0, theta=0.4)]
+    wants = [oracle_frame(oracle, kifs, screen, cam, gui, iters) for cam in cams]
+    if len(cams) == 1:
+        got = [gpu_frame(gs, screen, cams[0], gui, iters)]
+    else:
+        gs.update_screen_data(screen)
+        gs.update_options(gui)
+        gs.set_iters(*iters)
+        outs = [torch.zeros((96, 160, 4), dtype=torch.uint8, device="cuda:0") for _ in cams]
+        stream = torch.cuda.Stream()
+        gs.render_batch_async(outs, cams, stream=stream)
+        stream.synchronize()
+        got = [o.cpu().numpy() for o in outs]
+    for g, w_ in zip(got, wants):
+        assert diff_report(g, w_)["mismatched_pixels"] == 0, what
+    if what == "far_origin_batched":
+        assert (wants[0][..., :3] != wants[0][0, 0, :3]).any()
+
+
 def test_unknown_primitive_is_all_background(gs, kifs, oracle):
     gui = kifs.GuiData(background_color=(30, 60, 90))
     u = gui.into_buffer_data()
