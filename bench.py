@@ -699,11 +699,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             trial[cand] = float(t.item())
             del sf, step
-            torch.cuda.empty_cache()  # the trial's frame buffers must not sit beside the next one's
+            # (no empty_cache() between trials: rank 0's frame buffers have the same size in every trial, so the
+            # caching allocator hands them straight back; returning gigabytes to the driver instead makes it scrub
+            # them in the background, and whatever is timed in the next second reads up to twice too high --
+            # tools/fresh_memory_probe.py, profiles/r03/README.md)
             if args.gather == "dense" and len(trial) >= 3:
                 times = list(trial.values())
                 if times[-1] > times[-2] > times[-3]:  # past the minimum: larger shares only get slower
                     break
+        torch.cuda.empty_cache()  # once, before the real pipeline is built (the settle phase follows)
         floor = min(trial.values())
         best = min((c for c in trial if trial[c] <= 1.02 * floor), key=lambda c: (max(c) / min(c), trial[c]))
         return best, {"ms_per_step_by_share": {f"{c[0]}:{c[1]}": round(v * 1e3, 4) for c, v in trial.items()}}
