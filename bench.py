@@ -104,6 +104,10 @@ def parse():
                          "driving all N devices through kifs_multi_render_batch_async (RCCL inside the library)")
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "copy"],
                     help="--host one-process: the library's transport (auto = RCCL on distinct devices, peer copies otherwise)")
+    ap.add_argument("--one-process-secondary", default="auto", choices=["auto", "off"],
+                    help="N > 1, per-GPU host, row shards: once every collective of this job is done, rank 0 also runs the "
+                         "ONE-process form (kifs_multi_render_batch_async: RCCL inside the library) in a child process with "
+                         "a time limit and reports it as secondary.one_process_c_abi; 'off' skips it")
     ap.add_argument("--whole-orbit", action="store_true",
                     help="N = 1: a step is the workload's WHOLE orbit (max(frames, 120) poses, every frame resident in HBM) "
                          "in launches of --frames-per-launch frames")
@@ -854,6 +858,46 @@ def main():
         per_rank_kernel_ms = [m["kernel_ms"]]
         per_rank_step_ms = [m["elapsed"] / args.steps * 1e3]
 
+    # ---- N > 1: the same node once more through the C ABI's one-process path.  Every collective of this job is
+    # behind us: the other ranks are finished (they release their process group and leave), rank 0 frees its
+    # buffers and starts ONE child that drives all N devices itself -- kifs_multi_render_batch_async with RCCL inside
+    # the library -- under a time limit: a child that fails or hangs costs a field of the line, not the line.
+    one_proc = None
+    rows_per_rank = list(pipe.rows) if sharded else None
+    tiles_sent_fraction = (round(pipe.records_sent / pipe.tiles_seen, 4)
+                           if sharded and args.gather == "sparse" and getattr(pipe, "tiles_seen", 0) else None)
+    if world > 1 and sharded and args.one_process_secondary == "auto" and not args.no_secondary:
+        if rank != 0:
+            for g in gss:
+                g.close()
+            dist.destroy_process_group()
+            return
+        del pipe, step
+        torch.cuda.empty_cache()
+        child_env = {k: v for k, v in os.environ.items()
+                     if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                  "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(world), "--host", "one-process",
+               "--steps", str(min(args.steps, 40)), "--warmup", str(min(args.warmup, 8)), "--workload", key,
+               "--frames-per-launch", str(B), "--gather", args.gather, "--scaling", args.scaling, "--camera", args.camera,
+               "--encode", str(args.encode), "--cpu-seconds", "0", "--no-secondary"] + (["--share-device"] if args.share_device else [])
+        try:
+            cp = subprocess.run(cmd, env=child_env, capture_output=True, text=True, timeout=180)
+            lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+            if cp.returncode == 0 and len(lines) == 1:
+                d = json.loads(lines[0])
+                one_proc = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                               "frames_per_step": d["config"]["frames_per_step"], "comm": d.get("comm"),
+                               "per_rank_kernel_ms": d.get("per_rank_kernel_ms"),
+                               "note": "ONE process drives all the devices through kifs_multi_render_batch_async (C ABI); "
+                                       "run in a child process after this job's own collectives"}
+            else:
+                one_proc = {"error": f"exit code {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
+        except subprocess.TimeoutExpired:
+            one_proc = {"error": "no result within 180 s (the child was stopped)"}
+        except Exception as e:  # the main line must not depend on this
+            one_proc = {"error": repr(e)[:300]}
+
     if rank == 0:
         mpix = frames_per_step * W * H * args.steps / elapsed / 1e6
         bunny = int(w.gui.fractal_group) == 0 and int(w.gui.primitive_shape) == 5
@@ -929,10 +973,10 @@ def main():
         if sharded:
             out["config"]["root_weight"] = root_weight[0]
             out["config"]["peer_weight"] = root_weight[1]
-            out["config"]["rows_per_rank"] = pipe.rows
+            out["config"]["rows_per_rank"] = rows_per_rank
             out["config"]["gather"] = args.gather
-            if args.gather == "sparse" and pipe.tiles_seen:
-                out["config"]["tiles_sent_fraction"] = round(pipe.records_sent / pipe.tiles_seen, 4)
+            if tiles_sent_fraction is not None:
+                out["config"]["tiles_sent_fraction"] = tiles_sent_fraction
             if calibration:
                 out["config"]["root_weight_calibration"] = calibration
         if pmc and pmc.get("valu_instructions_per_launch") and pmc.get("kernel_cycles"):
@@ -946,6 +990,8 @@ def main():
                                              "kernel_cycles": pmc["kernel_cycles"], "simds": 1024,
                                              "cycles_per_plain_instruction": 2.25,
                                              "source": "profiles/pmc_traffic.json (rocprofv3 --pmc), tools/microbench/valu_rate.hip"}
+        if one_proc is not None:
+            secondary["one_process_c_abi"] = one_proc
         if secondary:
             out["secondary"] = secondary
         if check is not None:
@@ -957,7 +1003,7 @@ def main():
 
     for g in gss:
         g.close()
-    if world > 1:
+    if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
     if check is False:
         sys.exit("bench.py: gathered frames differ from single-GPU frames")

@@ -78,6 +78,11 @@ def test_two_ranks_are_started_by_bench_itself_and_gather_exact_frames():
     comm = d["comm"]
     assert comm["backend"].startswith("gloo") and comm["world_size_seen"] == 2 and comm["gather"] == "sparse"
     assert comm["check"] is True
+    # ... and, once the ranks' own collectives are over, the same two "devices" driven by ONE process through the C ABI
+    one = d["secondary"]["one_process_c_abi"]
+    assert "error" not in one, one
+    assert one["value"] > 1000.0 and one["frames_per_step"] == 8 and one["comm"]["check"] is True
+    assert one["comm"]["backend"] == "hip peer copies" and len(one["per_rank_kernel_ms"]) == 2
 
 
 def test_two_ranks_check_their_frames_by_default():
