@@ -302,8 +302,7 @@ def measure_workload(name, local_rank, B, steps, warmup, encode, camera_mode="or
     elapsed = time.perf_counter() - t0
     n, mean_ms, lo, hi = g.profile_read()
     g.set_profiling(0)
-    shape = ("render_wave_kernel" if g.debug_last_round_steps() > 0 and g.debug_last_group_tiles() == 0 else
-             "render_group_kernel" if g.debug_last_round_steps() > 0 else "render_kernel")
+    shape = g.debug_last_kernel()
     g.close()
     del bufs
     torch.cuda.empty_cache()
@@ -549,7 +548,8 @@ def main():
                 "kernel_ms": sum(r[0] * r[1] for r in reads) / max(n, 1),
                 "kernel_ms_min": min((r[2] for r in reads if r[0] > 0), default=0.0),
                 "kernel_ms_max": max((r[3] for r in reads if r[0] > 0), default=0.0),
-                "round_steps": gss[0].debug_last_round_steps(), "group_tiles": gss[0].debug_last_group_tiles()}
+                "round_steps": gss[0].debug_last_round_steps(), "group_tiles": gss[0].debug_last_group_tiles(),
+                "kernel": gss[0].debug_last_kernel()}
 
     def whole_frames(frames_per_launch, camera_mode, deliver=False):
         """Every rank renders whole frames: step k, rank r: frames (k N + r) b .. + b - 1 (at N = 1
@@ -900,10 +900,7 @@ def main():
 
     if rank == 0:
         mpix = frames_per_step * W * H * args.steps / elapsed / 1e6
-        bunny = int(w.gui.fractal_group) == 0 and int(w.gui.primitive_shape) == 5
-        kernel_name = ("render_wave_kernel" if m["round_steps"] > 0 and m["group_tiles"] == 0 else
-                       "render_group_kernel" if m["round_steps"] > 0 else
-                       "render_bunny_quad_kernel" if bunny else "render_kernel")
+        kernel_name = m["kernel"]
         # average duration of the dominant kernel over the timed region (per-launch event pairs);
         # ms_per_step additionally contains the inter-launch gaps and, at N > 1, the exchange
         launch_s = (m["kernel_ms"] if m["launches_timed"] else elapsed / args.steps * 1e3) / 1e3

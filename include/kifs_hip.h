@@ -393,7 +393,8 @@ int kifs_eval_points(kifs_ctx* ctx, const float* points_xyz, int n, float* sdf_o
  * `n` host values.  fn: 0 log, 1 log2, 2 exp2, 3 sin, 4 cos, 5 acos,
  * 6 pow(x, y) with y = `param`, 7 sRGB-encode (result as float code),
  * 8 UNORM-encode, 9 / 10 the mid-range reciprocal and square root of the generalised-Julia
- * step (correctly rounded for 2^-60 <= x < 2^60; tests check them exhaustively). */
+ * step (correctly rounded for 2^-60 <= x < 2^60; tests check them exhaustively), 11 the branch-free
+ * form of sin the bunny network uses (same values as 3). */
 int kifs_eval_math(kifs_ctx* ctx, int fn, const float* in, float param, float* out, int n);
 
 /* Diagnostics: with enable != 0, subsequent Julia renders write one record per wave into a
@@ -407,6 +408,15 @@ int kifs_debug_last_round_steps(kifs_ctx* ctx);
  * tile (render_wave_kernel), 1 or 2 = tiles per 256-thread workgroup (render_group_kernel), -1 = the
  * launch did not re-queue rays at all.  For tests and bench.py's kernel name. */
 int kifs_debug_last_group_tiles(kifs_ctx* ctx);
+/* Which render kernel the context's latest launch used (-1 before the first).  For tests and bench.py. */
+enum KifsKernel {
+    KIFS_KERNEL_BLOCK = 0,       /* render_kernel: one wave per 8x8 block, whole rays (the latency path) */
+    KIFS_KERNEL_GROUP = 1,       /* render_group_kernel: rays re-queued by a 256-thread workgroup */
+    KIFS_KERNEL_WAVE = 2,        /* render_wave_kernel: rays re-queued, one wave per tile */
+    KIFS_KERNEL_BUNNY_QUAD = 3,  /* render_bunny_quad_kernel: whole rays, four lanes per pixel */
+    KIFS_KERNEL_BUNNY_COOP = 4   /* render_bunny_coop_kernel: rays re-queued, four waves per 64 rays */
+};
+int kifs_debug_last_kernel(kifs_ctx* ctx);
 /* Tuning hooks: read / replace the order in which workgroups take the tiles of the full
  * frame (a permutation of (tile_x | tile_y << 16)); the order only affects speed. */
 int kifs_debug_get_tile_order(kifs_ctx* ctx, uint32_t* order, size_t max_count, size_t* count);

@@ -221,6 +221,7 @@ double kifs_last_kernel_ms(kifs_ctx* c) { return c ? c->last_ms : -1.0; }
 int kifs_debug_last_round_steps(kifs_ctx* c) { return c ? c->last_round_steps : -1; }
 
 int kifs_debug_last_group_tiles(kifs_ctx* c) { return c ? c->last_group_tiles : -2; }
+int kifs_debug_last_kernel(kifs_ctx* c) { return c ? c->last_kernel : -2; }
 
 int kifs_set_frames_in_flight(kifs_ctx* c, int n) {
     if (!c || n < 1) return KIFS_ERR_BAD_ARG;
@@ -391,7 +392,7 @@ int kifs_eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float
 }
 
 int kifs_eval_math(kifs_ctx* c, int fn, const float* in, float param, float* out, int n) {
-    if (!c || !in || !out || n < 0 || fn < 0 || fn > 10) return KIFS_ERR_BAD_ARG;
+    if (!c || !in || !out || n < 0 || fn < 0 || fn > 11) return KIFS_ERR_BAD_ARG;
     if (n == 0) return KIFS_OK;
     DeviceGuard g(c->device);
     float *d_in = nullptr, *d_out = nullptr;

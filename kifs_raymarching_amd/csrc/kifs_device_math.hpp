@@ -224,6 +224,20 @@ KIFS_DEV float sin_(float x) {
     return (q & 2) ? -s : s;
 }
 
+// sin_ without a branch: both kernels evaluated, everything else selects.  The same values (the kernels are
+// pure functions of r; lanes beyond the reduction's range reduce 0 instead and get x - x at the end), but
+// straight-line code: four of these interleave in the bunny network, where sin_'s three exec-mask regions each
+// would have fenced the scheduler and, in a diverged wave, run both kernels anyway.
+KIFS_DEV float sin_flat(float x) {
+    const bool ok = abs_(x) <= 1048576.0f;
+    float r;
+    const int q = reduce_pio2(ok ? x : 0.0f, r);
+    const float sk = sin_kernel(r), ck = cos_kernel(r);
+    const float s = (q & 1) ? ck : sk;
+    const float v = (q & 2) ? -s : s;
+    return ok ? v : x - x;
+}
+
 KIFS_DEV float cos_(float x) {
     if (!(abs_(x) <= 1048576.0f)) return x - x;
     float r;

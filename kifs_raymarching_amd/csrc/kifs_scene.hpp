@@ -375,6 +375,8 @@ KIFS_DEV V4 mat4_vec(const float* m, V4 v) {  // column-major 4x4 times vector
 }
 KIFS_DEV V4 add4(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 KIFS_DEV V4 sin4(V4 a) { return V4{sin_(a.x), sin_(a.y), sin_(a.z), sin_(a.w)}; }
+// the same values without branches (kifs_device_math.hpp), for the form whose dependent chain sets the frame time
+KIFS_DEV V4 sin4_flat(V4 a) { return V4{sin_flat(a.x), sin_flat(a.y), sin_flat(a.z), sin_flat(a.w)}; }
 KIFS_DEV V4 ld4(const float* v) { return V4{v[0], v[1], v[2], v[3]}; }
 
 KIFS_DEV float bunny_sdf(V3 p) {  // kifs.wgsl:84-137; weights in constant memory
@@ -997,19 +999,19 @@ KIFS_DEV V4 quad_lane4(V4 v) {
 KIFS_DEV float bunny_sdf_quad(const BunnyQuad& W, V3 p) {
     if (dot(p, p) > 1.0f) return length(p) - 0.8f;
     V4 q{p.x * -1.0f, p.z * 1.0f, p.y * -1.0f, 1.0f};
-    const V4 f0 = sin4(mat4_vec(W.w0, q));
+    const V4 f0 = sin4_flat(mat4_vec(W.w0, q));
     V4 a = mat4_vec(W.w1[0], quad_lane4<0>(f0));
     a = add4(a, mat4_vec(W.w1[1], quad_lane4<1>(f0)));
     a = add4(a, mat4_vec(W.w1[2], quad_lane4<2>(f0)));
     a = add4(a, mat4_vec(W.w1[3], quad_lane4<3>(f0)));
     a = add4(a, ld4(W.b1));
-    const V4 f1 = add4(sin4(a), f0);
+    const V4 f1 = add4(sin4_flat(a), f0);
     a = mat4_vec(W.w2[0], quad_lane4<0>(f1));
     a = add4(a, mat4_vec(W.w2[1], quad_lane4<1>(f1)));
     a = add4(a, mat4_vec(W.w2[2], quad_lane4<2>(f1)));
     a = add4(a, mat4_vec(W.w2[3], quad_lane4<3>(f1)));
     a = add4(a, ld4(W.b2));
-    const V4 sn = sin4(a);
+    const V4 sn = sin4_flat(a);
     const V4 f2{sn.x / 1.4f + f1.x, sn.y / 1.4f + f1.y, sn.z / 1.4f + f1.z, sn.w / 1.4f + f1.w};
     const float d = dot(f2, ld4(W.wo));
     float r = quad_lane<0>(d);
@@ -1017,6 +1019,72 @@ KIFS_DEV float bunny_sdf_quad(const BunnyQuad& W, V3 p) {
     r = r + quad_lane<2>(d);
     r = r + quad_lane<3>(d);
     return r - 0.16f;
+}
+
+// ---- the bunny, four WAVES per 64 pixels ---------------------------------------------------------
+// The quad form above keeps a column group's 156 weights in VGPRs: 216 registers, two waves per SIMD, and a wave
+// is one dependent chain -- the vector pipes are 28 % busy (profiles/r03).  Throughput launches turn the mapping
+// by ninety degrees: the four waves of a workgroup evaluate the network for the SAME 64 points, wave j computing
+// column group j.  The group index is then wave-uniform, so the weights are scalar loads from constant memory and
+// scalar operands of the fmas (no VGPRs at all), and the other groups' activations come through LDS: per estimate
+// three exchanges of 4 KB / 4 KB / 1 KB with a workgroup barrier each, instead of 156 registers per lane.  The four
+// waves carry identical ray state, so their control flow is identical and every barrier is reached by all of them.
+// Same operations on the same values in the same order as bunny_sdf: bit-identical.
+// (Tried and dropped, r03: the next layer's first two matrices loaded in front of the barrier -- 22 -> 56 SGPR spills,
+// 51.8 -> 36.8 Gpixel/s with this sine, 50.1 -> 49.0 with sin_flat; a latency kernel of this form, one workgroup per
+// 64 pixels and no queue -- lone 1080p frame 0.50 ms against the quad form's 0.38: gpurun_out sweep kept as
+// profiles/r03/sweep_bunny_variants.txt.)
+struct BunnyCoop {
+    float (*a)[4][64];  // [group][component][lane]: layer-0 activations
+    float (*b)[4][64];  // layer-1 activations
+    float (*c)[64];     // [group][lane]: the groups' partial dot products
+    int j;              // this wave's column group (wave-uniform)
+};
+KIFS_DEV V4 coop_load(float (*x)[4][64], int g, uint32_t lane) {
+    return V4{x[g][0][lane], x[g][1][lane], x[g][2][lane], x[g][3][lane]};
+}
+KIFS_DEV void coop_store(float (*x)[4][64], int g, uint32_t lane, V4 v) {
+    x[g][0][lane] = v.x;
+    x[g][1][lane] = v.y;
+    x[g][2][lane] = v.z;
+    x[g][3][lane] = v.w;
+}
+// (the sine with its branches here, sin_flat in the quad form -- measured both ways: 48 frames per launch 51.8 against
+// 50.1 Gpixel/s here, where the vector pipe is the limit and a wave whose lanes all take one kernel skips the other;
+// the quad form's lone frame 0.461 -> 0.377 ms with sin_flat, where the dependent chain is)
+KIFS_DEV float bunny_sdf_coop(const BunnyCoop& X, V3 p) {
+    const bool far = dot(p, p) > 1.0f;
+    const float outside = length(p) - 0.8f;
+    // (uniform over the workgroup: every wave holds the same points)
+    if (__builtin_amdgcn_ballot_w64(!far) == 0ull) return outside;
+    const uint32_t lane = __lane_id();
+    const int j = X.j;
+    V4 q{p.x * -1.0f, p.z * 1.0f, p.y * -1.0f, 1.0f};
+    const V4 f0 = sin4(mat4_vec(KIFS_BUNNY_L0[j], q));
+    coop_store(X.a, j, lane, f0);
+    __syncthreads();
+    V4 a = mat4_vec(KIFS_BUNNY_L1[j][0], coop_load(X.a, 0, lane));
+    a = add4(a, mat4_vec(KIFS_BUNNY_L1[j][1], coop_load(X.a, 1, lane)));
+    a = add4(a, mat4_vec(KIFS_BUNNY_L1[j][2], coop_load(X.a, 2, lane)));
+    a = add4(a, mat4_vec(KIFS_BUNNY_L1[j][3], coop_load(X.a, 3, lane)));
+    a = add4(a, ld4(KIFS_BUNNY_B1[j]));
+    const V4 f1 = add4(sin4(a), f0);
+    coop_store(X.b, j, lane, f1);
+    __syncthreads();
+    a = mat4_vec(KIFS_BUNNY_L2[j][0], coop_load(X.b, 0, lane));
+    a = add4(a, mat4_vec(KIFS_BUNNY_L2[j][1], coop_load(X.b, 1, lane)));
+    a = add4(a, mat4_vec(KIFS_BUNNY_L2[j][2], coop_load(X.b, 2, lane)));
+    a = add4(a, mat4_vec(KIFS_BUNNY_L2[j][3], coop_load(X.b, 3, lane)));
+    a = add4(a, ld4(KIFS_BUNNY_B2[j]));
+    const V4 sn = sin4(a);
+    const V4 f2{sn.x / 1.4f + f1.x, sn.y / 1.4f + f1.y, sn.z / 1.4f + f1.z, sn.w / 1.4f + f1.w};
+    X.c[j][lane] = dot(f2, ld4(KIFS_BUNNY_OUT[j]));
+    __syncthreads();
+    float r = X.c[0][lane];
+    r = r + X.c[1][lane];
+    r = r + X.c[2][lane];
+    r = r + X.c[3][lane];
+    return far ? outside : r - 0.16f;
 }
 
 // Ray of one pixel, marched by the four lanes of a quad together.

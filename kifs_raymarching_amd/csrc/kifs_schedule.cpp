@@ -48,6 +48,11 @@ constexpr double PAIR_FROM_BATCH = 3500.0;    // two tiles per 256-thread workgr
                                               //   below it pairing halves the workgroups side by side: 720p x8 0.222 -> 0.188 with one)
 constexpr double PAIR_FROM_GENJULIA = 12000.0;  // generalised Julia (1080p x32 0.140 -> 0.125 ms per frame; x8 nothing)
 constexpr double PAIR_FROM_LONE_KIFS = 12000.0; // a big lone KIFS frame (1440p Sierpinski at distance 2: -11 %)
+// the bunny (tools/sweep_bunny_coop.sh -> profiles/r03/sweep_bunny_coop.txt; 1080p at distance 5 is 149 heavy tiles a frame):
+constexpr double BUNNY_ROUNDS_FROM = 450.0;   // below: whole rays, four lanes per pixel (x2: 0.421 against 0.528 ms; x4: 0.592 against 0.536)
+constexpr double BUNNY_PAIR_FROM = 1800.0;    // two tiles per workgroup (x8: 25.7 -> 23.4 Gpixel/s; x16: 28.3 -> 35.9)
+constexpr int ROUND_STEPS_BUNNY_COOP = 4;     // its rounds (x48: 1/2/3/4/6/8 steps -> 52.2/53.6/53.8/53.5/53.3/52.8 Gpixel/s; the lanes-per-ray form: 4-8 alike)
+constexpr double BUNNY_COOP_FROM = 3500.0;    // four waves per 64 rays (x16: 35.9 against 30.4; x24: 37.4 / 37.2; x32: 36.7 / 44.4; x48: 37.4 / 51.8)
 }  // namespace rules
 
 int tuning_knob(const char* name) {
@@ -208,6 +213,7 @@ int fill_params(const kifs_ctx* c, kifs::FrameParams* P) {
     P->counters = c->d_counters;
     P->workgroups_per_cu = 0;
     P->group_tiles = 1;
+    P->bunny_coop = 0;
     return KIFS_OK;
 }
 
@@ -556,8 +562,8 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     if (P.round_steps == rules::ROUND_STEPS_JULIA && count == 1 && group_id == uint32_t(kifs::GROUP_JULIA) && P.max_iterations >= 64 &&
         tuning_knob("KIFS_ROUND_STEPS") < 0)
         P.round_steps = rules::ROUND_STEPS_LONE_JULIA;
-    // (nor does the lone bunny frame: 0.461 ms with the quad kernel, 0.670 ms in rounds)
-    if (bunny_scene && count == 1) P.round_steps = 0;
+    // (nor does the lone bunny frame: 0.461 ms with the quad kernel, 0.670 ms in rounds; nor two of them)
+    if (bunny_scene && (count == 1 || (load < rules::BUNNY_ROUNDS_FROM && tuning_knob("KIFS_ROUND_STEPS") < 0))) P.round_steps = 0;
     // nor does a launch too small to fill the device twice over (256x256 x 8 views = 2048
     // workgroups: 0.038 ms without, 0.062 ms with)
     if (uint64_t(tt->count) * uint64_t(count) < rules::REQUEUE_MIN_WORKGROUPS) P.round_steps = 0;
@@ -589,7 +595,14 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         else if (!lone && load >= (genjulia ? rules::PAIR_FROM_GENJULIA : rules::PAIR_FROM_BATCH)) shape = 2;
         else if (lone && kifs_scene && load >= rules::PAIR_FROM_LONE_KIFS) shape = 2;
         if (forced >= 0) shape = forced;
-        if (bunny_scene) shape = 1;
+        P.bunny_coop = 0;
+        if (bunny_scene) {  // its own rules: four lanes per ray (216 VGPRs) or four waves per 64 rays
+            static const int coop = tuning_knob("KIFS_BUNNY_COOP");
+            P.bunny_coop = coop >= 0 ? coop : (load >= rules::BUNNY_COOP_FROM ? 1 : 0);
+            shape = P.bunny_coop ? 2 : forced >= 1 ? forced : (load >= rules::BUNNY_PAIR_FROM ? 2 : 1);
+            if (P.bunny_coop && P.round_steps == rules::ROUND_STEPS_OTHER && tuning_knob("KIFS_ROUND_STEPS") < 0)
+                P.round_steps = rules::ROUND_STEPS_BUNNY_COOP;
+        }
         P.group_tiles = shape;
     }
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
@@ -602,6 +615,9 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     }
     c->last_round_steps = P.round_steps;
     c->last_group_tiles = P.round_steps > 0 ? P.group_tiles : -1;
+    c->last_kernel = P.round_steps > 0 ? (bunny_scene ? (P.bunny_coop ? KIFS_KERNEL_BUNNY_COOP : KIFS_KERNEL_GROUP)
+                                                      : (P.group_tiles == 0 ? KIFS_KERNEL_WAVE : KIFS_KERNEL_GROUP))
+                                       : (bunny_scene ? KIFS_KERNEL_BUNNY_QUAD : KIFS_KERNEL_BLOCK);
     if (big) {
         if (!hip_ok(hipMemcpyAsync(c->d_views[vs], c->h_views[vs], sizeof(kifs::BatchView) * size_t(count),
                                    hipMemcpyHostToDevice, stream), "copy(view table)"))

@@ -480,6 +480,14 @@ class GraphicState:
         workgroup (render_group_kernel), -1 = no ray re-queuing."""
         return int(lib.kifs_debug_last_group_tiles(self._ctx))
 
+    KERNEL_NAMES = ("render_kernel", "render_group_kernel", "render_wave_kernel", "render_bunny_quad_kernel",
+                    "render_bunny_coop_kernel")
+
+    def debug_last_kernel(self) -> str:
+        """Name of the render kernel the latest launch used ("" before the first)."""
+        k = int(lib.kifs_debug_last_kernel(self._ctx))
+        return self.KERNEL_NAMES[k] if 0 <= k < len(self.KERNEL_NAMES) else ""
+
     def set_frames_in_flight(self, n: int):
         """Scheduling hint: the caller keeps n frames in flight on this device (one context and
         stream each).  n > 1 trades the lone-frame residency cap for throughput."""

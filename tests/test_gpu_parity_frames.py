@@ -174,7 +174,21 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
         for y0, y1 in [(0, H), (13, H - 21)]:
             s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cam, gui))
             want = oracle.render(s, c, o, oracle.iters(*iters), y0=y0, y1=y1, ext=ext)
-            if batched:  # a batch of two is never residency-capped
+            if scene.startswith("bunny"):
+                # the bunny's throughput path has three forms, chosen by the launch's load (kifs_schedule.cpp): four
+                # lanes per ray with one or two tiles per workgroup, four waves per 64 rays from ~3500 heavy tiles
+                for views, kernel, tiles in ((2, "render_group_kernel", 1), (3, "render_group_kernel", 2),
+                                             (5, "render_bunny_coop_kernel", 2)):
+                    outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(views)]
+                    st = torch.cuda.Stream()
+                    gs.render_batch_async(outs, [cam] * views, stream=st, y0=y0, y1=y1)
+                    st.synchronize()
+                    assert (gs.debug_last_kernel(), gs.debug_last_group_tiles()) == (kernel, tiles), (scene, views)
+                    got = outs[-1].cpu().numpy()
+                    for o in outs[:-1]:
+                        assert (o.cpu().numpy() == got).all()
+                    assert diff_report(got, want)["mismatched_pixels"] == 0, (scene, y0, y1, views)
+            elif batched:  # a batch of two is never residency-capped
                 outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
                 st = torch.cuda.Stream()
                 gs.render_batch_async(outs, [cam, cam], stream=st, y0=y0, y1=y1)
@@ -183,8 +197,42 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
                 assert (outs[0].cpu().numpy() == got).all()
             else:
                 got = gs.render(y0=y0, y1=y1)
-            assert gs.debug_last_round_steps() == (16 if julia or scene == "genjulia" else 8), scene
+            # (the bunny's last launch is the one with four waves per 64 rays: rounds of 4)
+            assert gs.debug_last_round_steps() == (16 if julia or scene == "genjulia" else 4 if scene.startswith("bunny") else 8), scene
             assert diff_report(got, want)["mismatched_pixels"] == 0, (scene, y0, y1)
             assert (want[..., :3] != want[0, 0, :3]).any()
     finally:
         gs.set_extensions(soft_shadow=False)
+
+
+@pytest.mark.parametrize("encode", [0, 1])
+def test_bunny_four_waves_per_ray_chunk_equals_oracle(encode, gs, kifs, oracle):
+    """render_bunny_coop_kernel: the four waves of a workgroup march the same 64 rays, one column group of the
+    network each, activations through LDS.  Eight DIFFERENT views of a ragged frame (19 x 42 tiles, the last
+    column 24 pixels wide, the last row 5 high), cameras from inside the unit sphere (every tile heavy, rays that
+    start inside the network's domain) to 1.6 away, a short epsilon and a long one: three views per launch
+    against the oracle, pixel for pixel."""
+    import torch
+    PS = kifs.PrimitiveShape
+    W, H = 600, 333
+    screen = kifs.ScreenData(W, H)
+    gs.update_screen_data(screen)
+    gs.set_iters(100, 10, 10)
+    for eps, colour in ((1e-4, (240, 200, 90)), (2e-2, (20, 250, 130))):
+        gui = kifs.GuiData(primitive_shape=PS.Bunny, max_iterations=72, epsilon=eps, fractal_color=colour,
+                           background_color=(9, 30, 66))
+        gs.update_options(gui)
+        cams = [kifs.CameraData(origin_distance=d, min_distance=0.5, phi=0.7 * k, theta=0.25 * (k % 3) - 0.2)
+                for k, d in enumerate((1.3, 0.9, 1.45, 1.2, 1.6, 1.1, 1.3, 1.25))]
+        outs = torch.zeros((len(cams), H, W, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        st = torch.cuda.Stream()
+        gs.render_batch_async([outs[i] for i in range(len(cams))], cams, stream=st, encode=encode)
+        st.synchronize()
+        assert gs.debug_last_kernel() == "render_bunny_coop_kernel" and gs.debug_last_round_steps() == 4
+        got = outs.cpu().numpy()
+        for k in (1, 4, 7) if eps < 1e-3 else (0, 1):
+            s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cams[k], gui))
+            want = oracle.render(s, c, o, oracle.iters(100, 10, 10), encode=encode)
+            assert diff_report(got[k], want)["mismatched_pixels"] == 0, (eps, k)
+            assert (want[..., :3] != want[0, 0, :3]).any()

@@ -79,7 +79,7 @@ def test_sdf_and_normal_bit_exact(name, gui, iters, gs, kifs, oracle):
 
 
 MATH = [(0, "kor_logf"), (1, "kor_log2f"), (2, "kor_exp2f"), (3, "kor_sinf"), (4, "kor_cosf"),
-        (5, "kor_acosf")]
+        (5, "kor_acosf"), (11, "kor_sinf")]  # 11: sin_flat, the branch-free form in the bunny network
 
 
 def math_inputs(fn):
@@ -93,7 +93,7 @@ def math_inputs(fn):
                                (rng.integers(1, 0x00800000, 2000, dtype=np.uint32)).view(F)])
     elif fn == 2:
         body = rng.uniform(-160, 135, 300000).astype(F)
-    elif fn in (3, 4):
+    elif fn in (3, 4, 11):
         body = np.concatenate([rng.uniform(-40, 40, 200000), rng.uniform(-1e5, 1e5, 50000),
                                rng.uniform(-4e6, 4e6, 5000)]).astype(F)
     else:
@@ -101,7 +101,7 @@ def math_inputs(fn):
     return np.concatenate([special, body])
 
 
-@pytest.mark.parametrize("fn,oname", MATH, ids=[m[1] for m in MATH])
+@pytest.mark.parametrize("fn,oname", MATH, ids=[f"{m[1]}_{m[0]}" for m in MATH])
 def test_elementary_functions_bit_exact(fn, oname, gs, oracle):
     xs = math_inputs(fn)
     got = gs.eval_math(fn, xs)
