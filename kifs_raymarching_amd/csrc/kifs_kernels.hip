@@ -1313,3 +1313,15 @@ hipError_t launch_eval_math(int fn, const float* in, float param, const float* s
 }
 
 }  // namespace kifs
+
+#ifdef KIFS_EVAL_COUNT
+extern "C" int kifs_debug_eval_counts(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(kifs::g_eval_counts), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(kifs::g_eval_counts), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

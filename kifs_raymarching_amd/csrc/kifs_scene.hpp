@@ -996,7 +996,22 @@ KIFS_DEV V4 quad_lane4(V4 v) {
     return V4{quad_lane<M>(v.x), quad_lane<M>(v.y), quad_lane<M>(v.z), quad_lane<M>(v.w)};
 }
 
+#ifdef KIFS_EVAL_COUNT
+__device__ unsigned long long g_eval_counts[8];
+KIFS_DEV void eval_count(int slot, unsigned long long v) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+    if (__lane_id() == uint32_t(__builtin_ctzll(m))) atomicAdd(&g_eval_counts[slot], v);
+}
+#endif
 KIFS_DEV float bunny_sdf_quad(const BunnyQuad& W, V3 p) {
+#ifdef KIFS_EVAL_COUNT
+    eval_count(2, 1);
+    eval_count(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) / 4);
+    if (!(dot(p, p) > 1.0f)) {
+        eval_count(0, 1);
+        eval_count(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) / 4);
+    }
+#endif
     if (dot(p, p) > 1.0f) return length(p) - 0.8f;
     V4 q{p.x * -1.0f, p.z * 1.0f, p.y * -1.0f, 1.0f};
     const V4 f0 = sin4_flat(mat4_vec(W.w0, q));
@@ -1055,6 +1070,14 @@ KIFS_DEV void coop_store(float (*x)[4][64], int g, uint32_t lane, V4 v) {
 KIFS_DEV float bunny_sdf_coop(const BunnyCoop& X, V3 p) {
     const bool far = dot(p, p) > 1.0f;
     const float outside = length(p) - 0.8f;
+#ifdef KIFS_EVAL_COUNT
+    eval_count(2, 1);
+    if (X.j == 0) eval_count(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+    if (__builtin_amdgcn_ballot_w64(!far) != 0ull) {
+        eval_count(0, 1);
+        if (X.j == 0) eval_count(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(!far)));
+    }
+#endif
     // (uniform over the workgroup: every wave holds the same points)
     if (__builtin_amdgcn_ballot_w64(!far) == 0ull) return outside;
     const uint32_t lane = __lane_id();
