@@ -13,7 +13,9 @@ process after the timed region, `secondary.lone_frame` (one frame per launch: th
 `secondary.orbit_x8` (8 frames per launch), `secondary.fixed_camera` (the same view in all 8 slots
 of a batch: round 1's headline, the most favourable case for the tile-order feedback) and, for the headline
 workload, the north star's other sizes: `secondary.cfg4_julia_4096` (4096 x 4096, 512 / 16; batched and lone) and
-`secondary.ref_constants_1080p` (the reference's hard-coded 100 / 10 iterations and GUI-default constant).
+`secondary.ref_constants_1080p` (the reference's hard-coded 100 / 10 iterations and GUI-default constant), plus
+BASELINE configs 3 and 5: `secondary.cfg3_sierpinski_1080p` and `secondary.cfg5_whole_orbit` (the 120-frame 7680 x 4320
+orbit, all frames resident, timed in a child process under a time limit).
 
 N > 1 (one process per GPU; `python bench.py --gpus N` launches the N ranks itself, or it runs
 under torch.distributed.run): the north star's path.  Every frame is split into ROW SHARDS --
@@ -112,6 +114,10 @@ def parse():
                     help="N = 1: a step is the workload's WHOLE orbit (max(frames, 120) poses, every frame resident in HBM) "
                          "in launches of --frames-per-launch frames")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--cfg5-secondary", default="auto", choices=["auto", "off"],
+                    help="headline workload at N = 1: 'auto' also times BASELINE config 5 as it is named -- the whole 120-frame "
+                         "7680x4320 Sierpinski orbit, every frame resident (15.9 GB) -- in a child process under a time limit "
+                         "(secondary.cfg5_whole_orbit); 'off' skips it")
     return ap.parse_args()
 
 
@@ -312,6 +318,25 @@ def measure_workload(name, local_rank, B, steps, warmup, encode, camera_mode="or
             "ms_per_step": round(ms, 5), "ms_per_frame": round(ms / B, 5),
             "mpix_s": round(B * W * H / (ms * 1e-3) / 1e6, 2), "kernel": shape, "kernel_ms": round(k_ms, 5),
             "hbm_frac": round(B * 4.0 * W * H / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+
+
+def child_line(flags, limit_s, pick):
+    """Runs `bench.py <flags>` as a child under a time limit and returns pick(its JSON line), or {"error": ...}: a child
+    that fails or hangs costs a field of the line, not the line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        cp = subprocess.run([sys.executable, str(Path(__file__).resolve())] + flags, env=env, capture_output=True, text=True,
+                            timeout=limit_s)
+        lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+        if cp.returncode == 0 and len(lines) == 1:
+            return pick(json.loads(lines[0]))
+        return {"error": f"exit code {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {limit_s} s (the child was stopped)"}
+    except Exception as e:  # the main line must not depend on this
+        return {"error": repr(e)[:300]}
 
 
 def one_process(args):
@@ -830,6 +855,18 @@ def main():
                             "pixel / kernel time / 8 TB/s"}
                 secondary["ref_constants_1080p"] = measure_workload("ref_julia_1080p", local_rank, 48, sec_steps, sec_warm,
                                                                     args.encode)
+                # BASELINE configs 3 and 5: the Sierpinski pipeline at 1080p, and the 8K orbit as a whole
+                secondary["cfg3_sierpinski_1080p"] = measure_workload("cfg3_sierpinski_1080p", local_rank, 48, sec_steps, sec_warm,
+                                                                      args.encode)
+                if args.cfg5_secondary == "auto":
+                    torch.cuda.empty_cache()
+                    secondary["cfg5_whole_orbit"] = child_line(
+                        ["--workload", "cfg5_sierpinski_8k_orbit", "--whole-orbit", "--steps", "2", "--warmup", "1",
+                         "--frames-per-launch", "24", "--encode", str(args.encode), "--cpu-seconds", "0", "--no-secondary"],
+                        150, lambda d: {"orbit_ms": d["ms_per_step"], "mpix_s": d["value"], "frames": d["config"]["whole_orbit"]["frames"],
+                                        "frames_per_launch": d["config"]["frames_per_launch"], "kernel": d["roofline"]["kernel"],
+                                        "note": "all 120 frames of the 7680x4320 Sierpinski orbit (384 march steps, 10 folds), every "
+                                                "frame resident in HBM; one step = the whole orbit; run in a child process"})
         elif args.shard != "frames":
             p4, s4 = whole_frames(B, args.camera, deliver=False)
             mm = run(p4, s4, sec_steps, sec_warm)
@@ -874,29 +911,16 @@ def main():
             return
         del pipe, step
         torch.cuda.empty_cache()
-        child_env = {k: v for k, v in os.environ.items()
-                     if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
-                                  "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(world), "--host", "one-process",
-               "--steps", str(min(args.steps, 40)), "--warmup", str(min(args.warmup, 8)), "--workload", key,
-               "--frames-per-launch", str(B), "--gather", args.gather, "--scaling", args.scaling, "--camera", args.camera,
-               "--encode", str(args.encode), "--cpu-seconds", "0", "--no-secondary"] + (["--share-device"] if args.share_device else [])
-        try:
-            cp = subprocess.run(cmd, env=child_env, capture_output=True, text=True, timeout=180)
-            lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
-            if cp.returncode == 0 and len(lines) == 1:
-                d = json.loads(lines[0])
-                one_proc = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                               "frames_per_step": d["config"]["frames_per_step"], "comm": d.get("comm"),
-                               "per_rank_kernel_ms": d.get("per_rank_kernel_ms"),
-                               "note": "ONE process drives all the devices through kifs_multi_render_batch_async (C ABI); "
-                                       "run in a child process after this job's own collectives"}
-            else:
-                one_proc = {"error": f"exit code {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
-        except subprocess.TimeoutExpired:
-            one_proc = {"error": "no result within 180 s (the child was stopped)"}
-        except Exception as e:  # the main line must not depend on this
-            one_proc = {"error": repr(e)[:300]}
+        one_proc = child_line(
+            ["--gpus", str(world), "--host", "one-process", "--steps", str(min(args.steps, 40)), "--warmup", str(min(args.warmup, 8)),
+             "--workload", key, "--frames-per-launch", str(B), "--gather", args.gather, "--scaling", args.scaling,
+             "--camera", args.camera, "--encode", str(args.encode), "--cpu-seconds", "0", "--no-secondary"]
+            + (["--share-device"] if args.share_device else []), 180,
+            lambda d: {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                       "frames_per_step": d["config"]["frames_per_step"], "comm": d.get("comm"),
+                       "per_rank_kernel_ms": d.get("per_rank_kernel_ms"),
+                       "note": "ONE process drives all the devices through kifs_multi_render_batch_async (C ABI); "
+                               "run in a child process after this job's own collectives"})
 
     if rank == 0:
         mpix = frames_per_step * W * H * args.steps / elapsed / 1e6

@@ -48,7 +48,8 @@ def test_single_gpu_line_has_the_contract_fields():
     assert c["kind"] == "port" and c["unit"] == "Mpixels/s" and c["cores"] >= 1 and c["value"] > 0
     assert d["settle_steps"] == cfg["settle_steps_before_warmup"] > 0
     sec = d["secondary"]
-    assert set(sec) == {"lone_frame", "orbit_x8", "fixed_camera", "cfg4_julia_4096", "ref_constants_1080p"}
+    assert set(sec) == {"lone_frame", "orbit_x8", "fixed_camera", "cfg4_julia_4096", "ref_constants_1080p",
+                        "cfg3_sierpinski_1080p", "cfg5_whole_orbit"}
     assert sec["lone_frame"]["frames_per_launch"] == 1 and sec["orbit_x8"]["frames_per_launch"] == 8
     assert all(sec[k]["mpix_s"] > 0 and sec[k]["kernel_ms"] > 0 for k in ("lone_frame", "orbit_x8", "fixed_camera"))
     # the north star's 4096 x 4096 figure and the reference-constant run travel in the driver's own line
@@ -58,6 +59,13 @@ def test_single_gpu_line_has_the_contract_fields():
         assert c4[form]["mpix_s"] > 1000.0 and 0 < c4[form]["hbm_frac"] < 1 and c4[form]["kernel_ms"] > 0
     ref = sec["ref_constants_1080p"]
     assert ref["workload"] == "ref_julia_1080p" and ref["frames_per_launch"] == 48 and ref["mpix_s"] > 1000.0
+    c3 = sec["cfg3_sierpinski_1080p"]
+    assert c3["workload"] == "cfg3_sierpinski_1080p" and c3["frames_per_launch"] == 48 and c3["mpix_s"] > 1000.0
+    # BASELINE config 5 as it is named: the whole 120-frame 8K orbit, timed in a child process
+    c5 = sec["cfg5_whole_orbit"]
+    assert "error" not in c5, c5
+    assert c5["frames"] == 120 and c5["frames_per_launch"] == 24 and c5["kernel"] == "render_wave_kernel"
+    assert 20.0 < c5["orbit_ms"] < 2000.0 and abs(c5["mpix_s"] - 120 * 7680 * 4320 / (c5["orbit_ms"] * 1e-3) / 1e6) < 0.01 * c5["mpix_s"]
     assert d["per_rank_kernel_ms"] == [pytest.approx(r["kernel_ms"], rel=1e-3)]
 
 
