@@ -9,7 +9,7 @@ import kifs_raymarching_amd as K  # noqa: E402
 from kifs_raymarching_amd.configs import WORKLOADS  # noqa: E402
 
 dist = float(sys.argv[1]) if len(sys.argv) > 1 else 900.0
-for key in ["cfg2_julia_1080p", "cfg3_sierpinski_1080p", "cfg4_julia_4096", "cfg5_sierpinski_8k_orbit"]:
+for key in ["cfg2_julia_1080p", "cfg3_sierpinski_1080p", "n2_bunny_1080p", "n1_genjulia_1080p", "cfg4_julia_4096", "cfg5_sierpinski_8k_orbit"]:
     w = WORKLOADS[key]
     for d in (w.camera.origin_distance, dist):
         cam = K.CameraData(origin_distance=d, phi=w.camera.phi, theta=w.camera.theta)
