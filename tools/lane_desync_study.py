@@ -73,6 +73,9 @@ def price_round(seq_out, seq_trips, seq_len):
     return lock, res[0], res[1]
 
 
+SORT = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--sort=")), "")
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     key = args[0] if args else "cfg2_julia_1080p"
@@ -114,6 +117,16 @@ def main():
         if members is None or members.size == 0:
             return
         order = np.lexsort([members, tile[members]])  # tile, then pixel order within the tile (queue order ~ pixel order)
+        if SORT:
+            # what if a tile's rays were cut into waves by orbit length instead of pixel order?  key: the ray's trip count
+            # at its first step of the round ("first": what a predictor run at filing time could know exactly), its
+            # mean over the round ("mean": an oracle), or both with outside steps counted as -1
+            if SORT == "first":
+                key = np.where(rec_out[:, 0], -1, rec_tr[:, 0])
+            else:
+                w_ = np.arange(rec_tr.shape[1])[None, :] < rec_len[:, None]
+                key = (np.where(rec_out, 0, rec_tr) * w_).sum(1) / np.maximum(1, rec_len)
+            order = np.lexsort([members, -key, tile[members]])
         tl = tile[members][order]
         first = np.r_[0, np.nonzero(np.diff(tl))[0] + 1]
         start = np.zeros(tl.size, dtype=np.int64)
