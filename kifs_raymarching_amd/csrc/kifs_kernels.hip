@@ -700,15 +700,18 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const BatchPar
 template <int T>
 __global__ __launch_bounds__(BLOCK) void render_bunny_coop_kernel(const BatchParams B) {
     constexpr uint32_t CAP = uint32_t(BLOCK) * T;
-    __shared__ float s_srgb[256];
-    __shared__ uint32_t s_tile[T][TILE_H][TILE_W];
+    // LDS: 24 KB -- six workgroups per CU (at 30 KB, five: 53.8 against 55.8 Gpixel/s at 48 frames per launch).  Pixel ids as 16-bit words, the sRGB
+    // thresholds read from memory (only hit pixels are encoded), the staging tiles in queue buffer 0 once the march
+    // is over (as in render_wave_kernel).
     __shared__ uint32_t s_tiles[T];
     __shared__ int s_rows[T];
-    __shared__ uint32_t q_pix[2][CAP];
+    __shared__ uint16_t q_pix[2][CAP];
     __shared__ float q_t[2][CAP];
     __shared__ float s_dir[3][CAP];
-    __shared__ uint32_t h_pix[CAP];
+    __shared__ uint16_t h_pix[CAP];
     __shared__ float h_t[CAP];
+    static_assert(sizeof(uint32_t) * T * TILE_H * TILE_W == sizeof(float) * CAP, "the staging tiles fill queue buffer 0 exactly");
+    uint32_t (*const s_tile)[TILE_H][TILE_W] = reinterpret_cast<uint32_t (*)[TILE_H][TILE_W]>(&q_t[0][0]);
     __shared__ uint32_t q_count[3], h_count;
     __shared__ float x_a[4][4][64], x_b[4][4][64], x_c[4][64];  // the network's exchanges
 
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_coop_kernel(const BatchPar
     const FrameParams P = batch_frame(B, view);
     const int tid = threadIdx.x;
     const bool srgb = (P.encode == 1);
-    if (srgb) s_srgb[tid] = P.srgb_table[tid];
+    const float* const s_srgb = P.srgb_table;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lx = (wave << 3) | (lane & 7);  // set-up: wave w -> 8x8 block w of a tile
     const int ly = lane >> 3;
@@ -736,8 +739,6 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_coop_kernel(const BatchPar
         s_tiles[tid] = tile;
         s_rows[tid] = tile != 0xffffffffu ? tile_frame_row(P, tile >> 16) : 0;
     }
-#pragma unroll
-    for (int j = 0; j < T; ++j) s_tile[j][ly][lx] = P.background_rgba;
     __syncthreads();
 
     // ---- round 0's queue: the rays that survive the culls (one lane per pixel, the four waves side by side)
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_coop_kernel(const BatchPar
         if (alive) {
             const uint32_t i = base + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
             const uint32_t pix = (uint32_t(j) << 8) | (uint32_t(ly) << 5) | uint32_t(lx);
-            q_pix[0][i] = pix;
+            q_pix[0][i] = uint16_t(pix);
             q_t[0][i] = 0.0f;
             s_dir[0][pix] = dir.x;
             s_dir[1][pix] = dir.y;
@@ -808,11 +809,11 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_coop_kernel(const BatchPar
                 const uint32_t bh = h_count, bq = q_count[cnt_next];
                 if (hit) {
                     const uint32_t i = bh + uint32_t(__builtin_popcountll(mh & below));
-                    h_pix[i] = pix;
+                    h_pix[i] = uint16_t(pix);
                     h_t[i] = t;
                 } else if (marching) {
                     const uint32_t i = bq + uint32_t(__builtin_popcountll(mq & below));
-                    q_pix[cur ^ 1u][i] = pix;
+                    q_pix[cur ^ 1u][i] = uint16_t(pix);
                     q_t[cur ^ 1u][i] = t;
                 }
                 if (lane == 0) {
@@ -825,6 +826,10 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_coop_kernel(const BatchPar
         __syncthreads();  // the next queue and the hit list are complete
     }
 
+    // ---- the queues are dead: buffer 0 becomes the staging tiles, background first
+#pragma unroll
+    for (int j = 0; j < T; ++j) s_tile[j][ly][lx] = P.background_rgba;
+    __syncthreads();
     // ---- shade the hits, 64 at a time by all four waves
     const uint32_t hits = h_count;  // uniform
     for (uint32_t i0 = 0; i0 < hits; i0 += 64u) {

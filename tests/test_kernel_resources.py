@@ -32,7 +32,7 @@ def _budget(name):
     """(max VGPRs, min waves per SIMD) for a kernel by its demangled name."""
     m = re.search(r"render(?:_group|_wave)?_kernel<(\d+), (\d+)(?:, (\d+))?>", name)
     if "bunny_coop" in name:
-        return 64, 5                       # weights as scalar operands; 30 KB of LDS allow five workgroups per CU
+        return 64, 6                       # weights as scalar operands; 24 KB of LDS allow six workgroups per CU
     if "bunny_quad" in name or (m and m.group(1) == "0" and m.group(2) == "5"):
         return 224, 2                      # the bunny keeps 156 weights per lane in registers
     if m:
