@@ -26,6 +26,9 @@ n=W*H; t=np.zeros(n,dtype=F); pos=[np.full(n,o[k],dtype=F) for k in range(3)]
 tile=(ys.ravel()//8)*((W+31)//32)+xs.ravel()//32
 step=0; useful=0; lock=0; lock_capped={4:0,8:0,12:0,16:0}; hist=np.zeros(101)
 wave_of=np.full(n,-1,dtype=np.int64)
+# what if a tile's rays were cut into waves by their LAST step's trip count (known at filing time) instead of pixel order?
+ROUND=int(sys.argv[1]) if len(sys.argv)>1 else 16
+wave_sorted=np.full(n,-1,dtype=np.int64); last_trips=np.zeros(n,dtype=np.int32); lock_sorted=0
 while live.any() and step<s.max_iterations:
     idx=np.nonzero(live)[0]
     p=[c[idx] for c in pos]
@@ -48,16 +51,25 @@ while live.any() and step<s.max_iterations:
         dist[ins]=(F(0.25)*np.log(qs)*np.sqrt(qs/dqs)).astype(F)
     hist+=np.bincount(trips[~outside],minlength=101)[:101]
     useful+=float(np.where(outside,OUT,TRIP*trips+TAIL).sum())
-    if step%16==0:
+    if step%ROUND==0:
         order=np.lexsort([idx,tile[idx]]); tl=tile[idx][order]
         first=np.r_[0,np.nonzero(np.diff(tl))[0]+1]; start=np.zeros(tl.size,dtype=np.int64); start[first]=first; start=np.maximum.accumulate(start)
         wid=(np.cumsum(np.r_[True,tl[1:]!=tl[:-1]])-1)*1000+(np.arange(tl.size)-start)//64
         wave_of[idx[order]]=wid
+        order=np.lexsort([idx,-last_trips[idx],tile[idx]]); tl=tile[idx][order]
+        first=np.r_[0,np.nonzero(np.diff(tl))[0]+1]; start=np.zeros(tl.size,dtype=np.int64); start[first]=first; start=np.maximum.accumulate(start)
+        wave_sorted[idx[order]]=(np.cumsum(np.r_[True,tl[1:]!=tl[:-1]])-1)*1000+(np.arange(tl.size)-start)//64
     _,inv=np.unique(wave_of[idx],return_inverse=True)
     mt=np.zeros(inv.max()+1); np.maximum.at(mt,inv,trips)
     anyin=np.zeros(inv.max()+1,dtype=bool); np.logical_or.at(anyin,inv,~outside)
     anyout=np.zeros(inv.max()+1,dtype=bool); np.logical_or.at(anyout,inv,outside)
     lock+=float((64*(np.where(anyin,TRIP*mt+TAIL,0)+np.where(anyout,OUT,0))).sum())
+    _,inv2=np.unique(wave_sorted[idx],return_inverse=True)
+    mt2=np.zeros(inv2.max()+1); np.maximum.at(mt2,inv2,trips)
+    ain=np.zeros(inv2.max()+1,dtype=bool); np.logical_or.at(ain,inv2,~outside)
+    aout=np.zeros(inv2.max()+1,dtype=bool); np.logical_or.at(aout,inv2,outside)
+    lock_sorted+=float((64*(np.where(ain,TRIP*mt2+TAIL,0)+np.where(aout,OUT,0))).sum())
+    last_trips[idx]=np.where(outside,-1,trips)
     for cap in lock_capped:
         # trips beyond `cap` are done elsewhere at full lane utilisation: wave pays min(mt,cap); excess lane-trips paid at 64/64
         excess=np.maximum(trips-cap,0).sum()
@@ -70,7 +82,8 @@ while live.any() and step<s.max_iterations:
     leaving=(NP._dot(pg,pg)>R2)&(NP._dot(pg,[dirv[k][go] for k in range(3)])>0)
     with np.errstate(invalid="ignore"): live[go]=(t[go]<s.max_distance)&~leaving
     step+=1
-print("steps",step,"lockstep/useful",lock/useful)
+print("steps",step,"rounds of",ROUND,"lockstep/useful",lock/useful)
+print("waves cut by the last step's trip count: cost/useful",lock_sorted/useful,"gain",lock/lock_sorted)
 for cap,v in lock_capped.items(): print("cap",cap,"cost/useful",v/useful,"gain",lock/v)
 tot=hist.sum(); cum=np.cumsum(hist*np.arange(101))
 print("inside evaluations",int(tot),"mean trips",float((hist*np.arange(101)).sum()/tot))
