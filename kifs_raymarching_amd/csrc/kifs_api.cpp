@@ -1,5 +1,5 @@
 // kifs_api.cpp -- the C ABI of include/kifs_hip.h: context lifetime, uniform upload,
-// frame render.  Host code only; kernels live in kifs_kernels.hip.
+// frame render.  Host code only; kernels live in the three *_kernels.hip files.
 //
 // A kifs_ctx plays the part of the reference's GraphicState (render/graphics.rs:25-37):
 // it owns the "device objects" (stream, events, the sRGB table in HBM, a scratch frame

@@ -1,4 +1,4 @@
-// kifs_internal.hpp -- launcher prototypes shared by kifs_api.cpp and kifs_kernels.hip.
+// kifs_internal.hpp -- launcher prototypes shared by the host code and the kernel files (kifs_kernels.hip, kifs_support_kernels.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -22,7 +22,7 @@
 //   wait(j)     flush(j) if still pending; host waits for rendered and gathered of step j
 //
 // Nothing on a GPU waits for the host, and the host blocks only in flush (on work enqueued a step earlier).
-// Host code only; kernels live in kifs_kernels.hip.
+// Host code only; kernels live in kifs_kernels.hip / kifs_support_kernels.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

@@ -58,11 +58,11 @@ struct FrameParams {
     // hand-written long-ray loop, [1] wave-steps taken on the general path, [2] entries into
     // the long-ray loop, [3] waves.  Enabled by kifs_debug_counters().
     unsigned long long* counters;
-    // Wave-level early exit (see wave_is_culled in kifs_kernels.hip): a cheaper, more conservative
+    // Wave-level early exit (see wave_is_culled in kifs_render_common.hpp): a cheaper, more conservative
     // form of the bounding-sphere cull, evaluated before any ray is set up.  0 disables it.
     float quick_cull_n2;                // 1.2 (B + epsilon)^2: well outside cull_n2
     float inv_height;                   // ~1 / height (the quick test needs no exact uv)
-    // Tile-level form of the same exit (tile_is_culled in kifs_kernels.hip): the quick test at the tile's
+    // Tile-level form of the same exit (tile_is_culled in kifs_render_common.hpp): the quick test at the tile's
     // centre against a sphere grown by what the tile subtends.  tile_cull_beta bounds the angle (radians)
     // between the centre's ray and any ray of a 32 x 8 tile; 0 disables the test (camera matrix not
     // orthonormal, frame under 64 rows, quick cull off).  tile_cull_sqrtk = sqrt(quick_cull_n2).

@@ -953,176 +953,4 @@ KIFS_DEV V3 shade_hit(const FrameParams& P, V3 p) {
             [&](V3 q) { return scene_normal<GROUP, PRIM>(P, q); });
 }
 
-// ---- the bunny, four lanes per pixel -------------------------------------------------------
-// The bunny network (kifs.wgsl:84-137) is 3000 instructions per estimate when one lane does it
-// all, and a frame's run time is the longest ray's estimates back to back (a lone wave issues
-// one instruction per ~5 cycles whatever it is).  But the network is four independent column
-// groups per layer: lane j of a quad computes group j of its pixel -- f0[j], f1[j], f2[j] and
-// the j-th partial dot product -- reading the other groups' activations through DPP quad_perm
-// operands (no extra instructions, no LDS).  A wave then holds 16 pixels and an estimate is
-// ~700 instructions per lane; every value is produced by the same operation sequence as in
-// bunny_sdf, so the result is bit-identical.  The four lanes of a quad carry identical ray
-// state, which keeps all control flow quad-uniform (DPP never reads an inactive lane).
-struct BunnyQuad {  // the weights of column group j, resident in VGPRs
-    float w0[16], w1[4][16], b1[4], w2[4][16], b2[4], wo[4];
-};
-
-KIFS_DEV void bunny_quad_load(BunnyQuad& W, int j) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) W.w0[e] = KIFS_BUNNY_L0[j][e];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            W.w1[m][e] = KIFS_BUNNY_L1[j][m][e];
-            W.w2[m][e] = KIFS_BUNNY_L2[j][m][e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        W.b1[e] = KIFS_BUNNY_B1[j][e];
-        W.b2[e] = KIFS_BUNNY_B2[j][e];
-        W.wo[e] = KIFS_BUNNY_OUT[j][e];
-    }
-}
-
-template <int M>
-KIFS_DEV float quad_lane(float v) {  // v of lane M of the caller's quad
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), M * 0x55, 0xf, 0xf, true));
-}
-template <int M>
-KIFS_DEV V4 quad_lane4(V4 v) {
-    return V4{quad_lane<M>(v.x), quad_lane<M>(v.y), quad_lane<M>(v.z), quad_lane<M>(v.w)};
-}
-
-#ifdef KIFS_EVAL_COUNT
-__device__ unsigned long long g_eval_counts[8];
-KIFS_DEV void eval_count(int slot, unsigned long long v) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
-    if (__lane_id() == uint32_t(__builtin_ctzll(m))) atomicAdd(&g_eval_counts[slot], v);
-}
-#endif
-KIFS_DEV float bunny_sdf_quad(const BunnyQuad& W, V3 p) {
-#ifdef KIFS_EVAL_COUNT
-    eval_count(2, 1);
-    eval_count(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) / 4);
-    if (!(dot(p, p) > 1.0f)) {
-        eval_count(0, 1);
-        eval_count(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) / 4);
-    }
-#endif
-    if (dot(p, p) > 1.0f) return length(p) - 0.8f;
-    V4 q{p.x * -1.0f, p.z * 1.0f, p.y * -1.0f, 1.0f};
-    const V4 f0 = sin4_flat(mat4_vec(W.w0, q));
-    V4 a = mat4_vec(W.w1[0], quad_lane4<0>(f0));
-    a = add4(a, mat4_vec(W.w1[1], quad_lane4<1>(f0)));
-    a = add4(a, mat4_vec(W.w1[2], quad_lane4<2>(f0)));
-    a = add4(a, mat4_vec(W.w1[3], quad_lane4<3>(f0)));
-    a = add4(a, ld4(W.b1));
-    const V4 f1 = add4(sin4_flat(a), f0);
-    a = mat4_vec(W.w2[0], quad_lane4<0>(f1));
-    a = add4(a, mat4_vec(W.w2[1], quad_lane4<1>(f1)));
-    a = add4(a, mat4_vec(W.w2[2], quad_lane4<2>(f1)));
-    a = add4(a, mat4_vec(W.w2[3], quad_lane4<3>(f1)));
-    a = add4(a, ld4(W.b2));
-    const V4 sn = sin4_flat(a);
-    const V4 f2{sn.x / 1.4f + f1.x, sn.y / 1.4f + f1.y, sn.z / 1.4f + f1.z, sn.w / 1.4f + f1.w};
-    const float d = dot(f2, ld4(W.wo));
-    float r = quad_lane<0>(d);
-    r = r + quad_lane<1>(d);
-    r = r + quad_lane<2>(d);
-    r = r + quad_lane<3>(d);
-    return r - 0.16f;
-}
-
-// ---- the bunny, four WAVES per 64 pixels ---------------------------------------------------------
-// The quad form above keeps a column group's 156 weights in VGPRs: 216 registers, two waves per SIMD, and a wave
-// is one dependent chain -- the vector pipes are 28 % busy (profiles/r03).  Throughput launches turn the mapping
-// by ninety degrees: the four waves of a workgroup evaluate the network for the SAME 64 points, wave j computing
-// column group j.  The group index is then wave-uniform, so the weights are scalar loads from constant memory and
-// scalar operands of the fmas (no VGPRs at all), and the other groups' activations come through LDS: per estimate
-// three exchanges of 4 KB / 4 KB / 1 KB with a workgroup barrier each, instead of 156 registers per lane.  The four
-// waves carry identical ray state, so their control flow is identical and every barrier is reached by all of them.
-// Same operations on the same values in the same order as bunny_sdf: bit-identical.
-// (Tried and dropped, r03: the next layer's first two matrices loaded in front of the barrier -- 22 -> 56 SGPR spills,
-// 51.8 -> 36.8 Gpixel/s with this sine, 50.1 -> 49.0 with sin_flat; a latency kernel of this form, one workgroup per
-// 64 pixels and no queue -- lone 1080p frame 0.50 ms against the quad form's 0.38: gpurun_out sweep kept as
-// profiles/r03/sweep_bunny_variants.txt.)
-struct BunnyCoop {
-    float (*a)[4][64];  // [group][component][lane]: layer-0 activations
-    float (*b)[4][64];  // layer-1 activations
-    float (*c)[64];     // [group][lane]: the groups' partial dot products
-    int j;              // this wave's column group (wave-uniform)
-};
-KIFS_DEV V4 coop_load(float (*x)[4][64], int g, uint32_t lane) {
-    return V4{x[g][0][lane], x[g][1][lane], x[g][2][lane], x[g][3][lane]};
-}
-KIFS_DEV void coop_store(float (*x)[4][64], int g, uint32_t lane, V4 v) {
-    x[g][0][lane] = v.x;
-    x[g][1][lane] = v.y;
-    x[g][2][lane] = v.z;
-    x[g][3][lane] = v.w;
-}
-// (the sine with its branches here, sin_flat in the quad form -- measured both ways: 48 frames per launch 51.8 against
-// 50.1 Gpixel/s here, where the vector pipe is the limit and a wave whose lanes all take one kernel skips the other;
-// the quad form's lone frame 0.461 -> 0.377 ms with sin_flat, where the dependent chain is)
-KIFS_DEV float bunny_sdf_coop(const BunnyCoop& X, V3 p) {
-    const bool far = dot(p, p) > 1.0f;
-    const float outside = length(p) - 0.8f;
-#ifdef KIFS_EVAL_COUNT
-    eval_count(2, 1);
-    if (X.j == 0) eval_count(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
-    if (__builtin_amdgcn_ballot_w64(!far) != 0ull) {
-        eval_count(0, 1);
-        if (X.j == 0) eval_count(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(!far)));
-    }
-#endif
-    // (uniform over the workgroup: every wave holds the same points)
-    if (__builtin_amdgcn_ballot_w64(!far) == 0ull) return outside;
-    const uint32_t lane = __lane_id();
-    const int j = X.j;
-    V4 q{p.x * -1.0f, p.z * 1.0f, p.y * -1.0f, 1.0f};
-    const V4 f0 = sin4(mat4_vec(KIFS_BUNNY_L0[j], q));
-    coop_store(X.a, j, lane, f0);
-    __syncthreads();
-    V4 a = mat4_vec(KIFS_BUNNY_L1[j][0], coop_load(X.a, 0, lane));
-    a = add4(a, mat4_vec(KIFS_BUNNY_L1[j][1], coop_load(X.a, 1, lane)));
-    a = add4(a, mat4_vec(KIFS_BUNNY_L1[j][2], coop_load(X.a, 2, lane)));
-    a = add4(a, mat4_vec(KIFS_BUNNY_L1[j][3], coop_load(X.a, 3, lane)));
-    a = add4(a, ld4(KIFS_BUNNY_B1[j]));
-    const V4 f1 = add4(sin4(a), f0);
-    coop_store(X.b, j, lane, f1);
-    __syncthreads();
-    a = mat4_vec(KIFS_BUNNY_L2[j][0], coop_load(X.b, 0, lane));
-    a = add4(a, mat4_vec(KIFS_BUNNY_L2[j][1], coop_load(X.b, 1, lane)));
-    a = add4(a, mat4_vec(KIFS_BUNNY_L2[j][2], coop_load(X.b, 2, lane)));
-    a = add4(a, mat4_vec(KIFS_BUNNY_L2[j][3], coop_load(X.b, 3, lane)));
-    a = add4(a, ld4(KIFS_BUNNY_B2[j]));
-    const V4 sn = sin4(a);
-    const V4 f2{sn.x / 1.4f + f1.x, sn.y / 1.4f + f1.y, sn.z / 1.4f + f1.z, sn.w / 1.4f + f1.w};
-    X.c[j][lane] = dot(f2, ld4(KIFS_BUNNY_OUT[j]));
-    __syncthreads();
-    float r = X.c[0][lane];
-    r = r + X.c[1][lane];
-    r = r + X.c[2][lane];
-    r = r + X.c[3][lane];
-    return far ? outside : r - 0.16f;
-}
-
-// Ray of one pixel, marched by the four lanes of a quad together.
-KIFS_DEV V3 raymarch_bunny_quad(const FrameParams& P, V3 dir, bool valid, int quad_lane_id, int& steps) {
-    const bool cull = (P.is_heatmap == 0u) && (P.cull_n2 > 0.0f);
-    const bool worth = valid && !(cull && ray_never_inside(P, dir));
-    if (__builtin_amdgcn_ballot_w64(worth) == 0ull) {  // nothing to march: skip the weight loads
-        steps = 0;
-        return P.background_color;
-    }
-    BunnyQuad W;
-    bunny_quad_load(W, quad_lane_id);
-    return raymarch_with(
-        P, dir, valid, steps, [&](V3 q, unsigned long long) { return bunny_sdf_quad(W, q); },
-        [&](V3 q) { return normal_fd(P.epsilon, q, [&](V3 u) { return bunny_sdf_quad(W, u); }); });
-}
-
 }  // namespace kifs

@@ -1,6 +1,6 @@
 // kifs_schedule.cpp -- one launch of the render path: kernel parameters from the uniform images, tile
 // tables and their temporal feedback, and the launch shape (which kernel form, how many tiles per
-// workgroup, residency).  Host code only; kernels live in kifs_kernels.hip.
+// workgroup, residency).  Host code only; kernels live in the three *_kernels.hip files.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>

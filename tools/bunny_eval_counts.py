@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How many network evaluations do the bunny's throughput kernels really run?  (diagnosis tool, r03)
 
-Needs a library built with the counting hooks (kifs_scene.hpp, #ifdef KIFS_EVAL_COUNT -- not in the shipped build):
+Needs a library built with the counting hooks (kifs_bunny.hpp, #ifdef KIFS_EVAL_COUNT -- not in the shipped build):
     make -C kifs_raymarching_amd/csrc -B EXTRA=-DKIFS_EVAL_COUNT OUT=../../build_variants/libkifs_count.so
     (GPU box)  cp build_variants/libkifs_count.so kifs_raymarching_amd/libkifs_hip.so
                KIFS_TUNING=1 KIFS_BUNNY_COOP=1 python tools/bunny_eval_counts.py 48
