@@ -42,7 +42,8 @@ constexpr int ROUND_STEPS_LONE_JULIA = 32;  // an uncapped lone Julia frame (409
 constexpr uint64_t REQUEUE_MIN_WORKGROUPS = 4096u;  // below: no rounds at all (256^2 x 8: 0.038 vs 0.062 ms)
 // shape of the re-queuing path, from profiles/r02/sweep_shapes.jsonl (every shape forced in turn):
 constexpr double WAVE_FROM_LONE = 30000.0;    // one wave per tile (render_wave_kernel) from this load: lone frames,
-constexpr double WAVE_FROM_JULIA = 16000.0;   //   batched Julia (1080p x32: 1.13 -> 0.88 ms; 4096^2 x8 +27 %),
+constexpr double WAVE_FROM_JULIA = 12500.0;   //   batched Julia (1080p x32: 1.13 -> 0.88 ms; 4096^2 x8 +27 %; re-swept r03 after the wave
+                                              //   kernel's +15 %: 1080p x16 63.9 against 65.8 with pairs, x20 70.5 against 66.6, x24 76.2 / 67.8),
 constexpr double WAVE_FROM_OTHER = 32000.0;   //   everything else (8K Sierpinski x4 +16 %)
 constexpr double PAIR_FROM_BATCH = 3500.0;    // two tiles per 256-thread workgroup: batches (1080p Julia 0.319 -> 0.281 ms;
                                               //   below it pairing halves the workgroups side by side: 720p x8 0.222 -> 0.188 with one)
@@ -572,7 +573,7 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         //   one WAVE per tile (render_wave_kernel) once the launch has several times more heavy tiles
         //     than the device has workgroup slots -- then slots, not critical paths, set its duration, and
         //     single-wave workgroups give four times as many (1080p Julia x32: 1.13 -> 0.88 ms; 4096^2 x8
-        //     +27 %; 8K Sierpinski x4 +16 %) -- from a load of 16 000 tiles for the Julia pipeline, 32 000
+        //     +27 %; 8K Sierpinski x4 +16 %) -- from a load of 12 500 tiles for the Julia pipeline, 32 000
         //     for the others, 30 000 for a lone frame (all its heavy tiles are one view's);
         //   otherwise 256-thread workgroups (render_group_kernel), whose four waves take a tile's first,
         //     crowded rounds side by side (a lone wave needs +30 % for the same tile): TWO tiles of the cost
