@@ -15,7 +15,8 @@ of a batch: round 1's headline, the most favourable case for the tile-order feed
 workload, the north star's other sizes: `secondary.cfg4_julia_4096` (4096 x 4096, 512 / 16; batched and lone) and
 `secondary.ref_constants_1080p` (the reference's hard-coded 100 / 10 iterations and GUI-default constant), plus
 BASELINE configs 3 and 5: `secondary.cfg3_sierpinski_1080p` and `secondary.cfg5_whole_orbit` (the 120-frame 7680 x 4320
-orbit, all frames resident, timed in a child process under a time limit).
+orbit with soft-shadow secondary rays, all frames resident, timed in a child process under a time limit;
+`secondary.cfg5_whole_orbit_reference_shading`: the same orbit without the extension).
 
 N > 1 (one process per GPU; `python bench.py --gpus N` launches the N ranks itself, or it runs
 under torch.distributed.run): the north star's path.  Every frame is split into ROW SHARDS --
@@ -860,13 +861,18 @@ def main():
                                                                       args.encode)
                 if args.cfg5_secondary == "auto":
                     torch.cuda.empty_cache()
-                    secondary["cfg5_whole_orbit"] = child_line(
-                        ["--workload", "cfg5_sierpinski_8k_orbit", "--whole-orbit", "--steps", "2", "--warmup", "1",
-                         "--frames-per-launch", "24", "--encode", str(args.encode), "--cpu-seconds", "0", "--no-secondary"],
-                        150, lambda d: {"orbit_ms": d["ms_per_step"], "mpix_s": d["value"], "frames": d["config"]["whole_orbit"]["frames"],
-                                        "frames_per_launch": d["config"]["frames_per_launch"], "kernel": d["roofline"]["kernel"],
-                                        "note": "all 120 frames of the 7680x4320 Sierpinski orbit (384 march steps, 10 folds), every "
-                                                "frame resident in HBM; one step = the whole orbit; run in a child process"})
+                    for name, wl, what in (("cfg5_whole_orbit", "cfg5_sierpinski_8k_orbit_shadows",
+                                            "with the soft-shadow secondary rays BASELINE config 5 names (an extension: the reference has none)"),
+                                           ("cfg5_whole_orbit_reference_shading", "cfg5_sierpinski_8k_orbit",
+                                            "the reference's own shading (no secondary rays)")):
+                        secondary[name] = child_line(
+                            ["--workload", wl, "--whole-orbit", "--steps", "2", "--warmup", "1", "--frames-per-launch", "24",
+                             "--encode", str(args.encode), "--cpu-seconds", "0", "--no-secondary"],
+                            150, lambda d, what=what: {
+                                "orbit_ms": d["ms_per_step"], "mpix_s": d["value"], "frames": d["config"]["whole_orbit"]["frames"],
+                                "frames_per_launch": d["config"]["frames_per_launch"], "kernel": d["roofline"]["kernel"],
+                                "note": "all 120 frames of the 7680x4320 Sierpinski orbit (384 march steps, 10 folds), " + what +
+                                        "; every frame resident in HBM; one step = the whole orbit; run in a child process"})
         elif args.shard != "frames":
             p4, s4 = whole_frames(B, args.camera, deliver=False)
             mm = run(p4, s4, sec_steps, sec_warm)

@@ -132,7 +132,8 @@ int kifs_set_iters(kifs_ctx* ctx, int sdf_iters, int normal_iters, int fold_iter
  *     res = 1; t = shadow_t0
  *     up to shadow_steps times: h = scene_SDF(start + t*L); if h < epsilon -> res = 0, stop;
  *                               res = min(res, shadow_k*h/t); t += h; stop if t > shadow_max_t
- * and the direct term is attenuated: diffuse = 0.1 + 0.9 * clamp(n.(1,1,1), 0, 1) * res.
+ * and the direct term is attenuated: diffuse = 0.1 + 0.9 * clamp(n.(1,1,1), 0, 1) * res.  A hit whose direct term
+ * is not positive (it faces away from the light) marches no secondary ray (res = 1: there is nothing to attenuate).
  * All zero (the default) is the reference's behaviour exactly. */
 typedef struct KifsExtensions {
     uint32_t soft_shadow;

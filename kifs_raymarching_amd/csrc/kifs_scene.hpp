@@ -799,7 +799,7 @@ KIFS_DEV V3 julia_shade(const FrameParams& P, V3 p) {
     float ndl = (n.x + n.y) + n.z;
     float lit = clamp_(ndl, 0.0f, 1.0f);
     if (__builtin_expect(P.soft_shadow != 0u, 0))
-        lit = lit * soft_shadow(P, p, n, true, [&](V3 q, unsigned long long) { return julia_sdf(P, q); });
+        lit = lit * soft_shadow(P, p, n, lit > 0.0f, [&](V3 q, unsigned long long) { return julia_sdf(P, q); });
     float diffuse = fmaf_(0.9f, lit, 0.1f);
     return V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
 }
@@ -889,7 +889,8 @@ KIFS_DEV V3 generic_shade(const FrameParams& P, V3 p, Sdf sdf, Normal normal) {
     V3 n = normal(p);
     float ndl = (n.x + n.y) + n.z;  // dot(n, (1,1,1)): the light is not normalised (:17)
     float lit = clamp_(ndl, 0.0f, 1.0f);
-    if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow(P, p, n, true, sdf);
+    // (a lane whose direct term is not positive marches no secondary ray: its factor is 1 and 0 * 1 = 0)
+    if (__builtin_expect(P.soft_shadow != 0u, 0)) lit = lit * soft_shadow(P, p, n, lit > 0.0f, sdf);
     float diffuse = fmaf_(0.9f, lit, 0.1f);
     return V3{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
 }

@@ -424,7 +424,8 @@ static v3 ray_direction(const Scene* s, int x, int y) {
  *         h = scene_SDF(start + t * L);  if h < epsilon: return 0      (occluded)
  *         res = min(res, (k * h) / t);   t = t + h;  if t > max_t: stop
  *     return res
- * Only the direct term is attenuated: diffuse = 0.1 + 0.9 * clamp(n.(1,1,1)) * res. */
+ * Only the direct term is attenuated: diffuse = 0.1 + 0.9 * clamp(n.(1,1,1)) * res -- and only where there is one:
+ * a hit whose direct term is not positive (it faces away from the light) marches no secondary ray. */
 static float soft_shadow(Scene* s, v3 p, v3 n) {
     const v3 L = normalize3((v3){1.0f, 1.0f, 1.0f});
     const float off = 2.0f * s->epsilon;
@@ -456,7 +457,7 @@ static int raymarch(Scene* s, v3 dir, float rgba[4], int* hit_out) {
             v3 n = scene_normal(s, p);                                /* :16 */
             float ndl = (n.x + n.y) + n.z; /* dot(n, (1,1,1)), :17 */
             float lit = clamp_(ndl, 0.0f, 1.0f);
-            if (s->ext.soft_shadow) lit = lit * soft_shadow(s, p, n); /* extension */
+            if (s->ext.soft_shadow && lit > 0.0f) lit = lit * soft_shadow(s, p, n); /* extension */
             float diffuse = fma_(0.9f, lit, 0.1f);
             out_r = diffuse * s->fractal_color.x;                     /* :19 */
             out_g = diffuse * s->fractal_color.y;

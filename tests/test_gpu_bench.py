@@ -49,7 +49,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["settle_steps"] == cfg["settle_steps_before_warmup"] > 0
     sec = d["secondary"]
     assert set(sec) == {"lone_frame", "orbit_x8", "fixed_camera", "cfg4_julia_4096", "ref_constants_1080p",
-                        "cfg3_sierpinski_1080p", "cfg5_whole_orbit"}
+                        "cfg3_sierpinski_1080p", "cfg5_whole_orbit", "cfg5_whole_orbit_reference_shading"}
     assert sec["lone_frame"]["frames_per_launch"] == 1 and sec["orbit_x8"]["frames_per_launch"] == 8
     assert all(sec[k]["mpix_s"] > 0 and sec[k]["kernel_ms"] > 0 for k in ("lone_frame", "orbit_x8", "fixed_camera"))
     # the north star's 4096 x 4096 figure and the reference-constant run travel in the driver's own line
@@ -62,10 +62,12 @@ def test_single_gpu_line_has_the_contract_fields():
     c3 = sec["cfg3_sierpinski_1080p"]
     assert c3["workload"] == "cfg3_sierpinski_1080p" and c3["frames_per_launch"] == 48 and c3["mpix_s"] > 1000.0
     # BASELINE config 5 as it is named: the whole 120-frame 8K orbit, timed in a child process
-    c5 = sec["cfg5_whole_orbit"]
-    assert "error" not in c5, c5
-    assert c5["frames"] == 120 and c5["frames_per_launch"] == 24 and c5["kernel"] == "render_wave_kernel"
-    assert 20.0 < c5["orbit_ms"] < 2000.0 and abs(c5["mpix_s"] - 120 * 7680 * 4320 / (c5["orbit_ms"] * 1e-3) / 1e6) < 0.01 * c5["mpix_s"]
+    for name in ("cfg5_whole_orbit", "cfg5_whole_orbit_reference_shading"):
+        c5 = sec[name]
+        assert "error" not in c5, c5
+        assert c5["frames"] == 120 and c5["frames_per_launch"] == 24 and c5["kernel"] == "render_wave_kernel"
+        assert 20.0 < c5["orbit_ms"] < 2000.0 and abs(c5["mpix_s"] - 120 * 7680 * 4320 / (c5["orbit_ms"] * 1e-3) / 1e6) < 0.01 * c5["mpix_s"]
+    assert sec["cfg5_whole_orbit"]["orbit_ms"] > sec["cfg5_whole_orbit_reference_shading"]["orbit_ms"]  # the secondary rays cost something
     assert d["per_rank_kernel_ms"] == [pytest.approx(r["kernel_ms"], rel=1e-3)]
 
 
