@@ -871,7 +871,7 @@ def main():
                             150, lambda d, what=what: {
                                 "orbit_ms": d["ms_per_step"], "mpix_s": d["value"], "frames": d["config"]["whole_orbit"]["frames"],
                                 "frames_per_launch": d["config"]["frames_per_launch"], "kernel": d["roofline"]["kernel"],
-                                "note": "all 120 frames of the 7680x4320 Sierpinski orbit (384 march steps, 10 folds), " + what +
+                                "note": "all 120 frames of the 7680x4320 Sierpinski orbit (256 march steps, 16 folds), " + what +
                                         "; every frame resident in HBM; one step = the whole orbit; run in a child process"})
         elif args.shard != "frames":
             p4, s4 = whole_frames(B, args.camera, deliver=False)
