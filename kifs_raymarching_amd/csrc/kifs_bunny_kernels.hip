@@ -45,17 +45,7 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_quad_kernel(const BatchPar
     __syncthreads();  // s_srgb visible
     uint32_t rgba = P.background_rgba;
     if (!culled) {
-        uint32_t r, g, b;
-        if (srgb) {
-            r = srgb8(colour.x, s_srgb);
-            g = srgb8(colour.y, s_srgb);
-            b = srgb8(colour.z, s_srgb);
-        } else {
-            r = unorm8(colour.x);
-            g = unorm8(colour.y);
-            b = unorm8(colour.z);
-        }
-        rgba = r | (g << 8) | (b << 16) | 0xff000000u;
+        rgba = encode_rgba(colour, srgb, s_srgb);
     }
     if (group == 0) s_tile[ly][lx] = rgba;
     __syncthreads();
@@ -219,17 +209,8 @@ __global__ __launch_bounds__(BLOCK) void render_bunny_coop_kernel(const BatchPar
         const V3 colour = generic_shade(P, p, sdf, [&](V3 q) {
             return normal_fd(P.epsilon, q, [&](V3 u) { return bunny_sdf_coop(X, u); });
         });
-        uint32_t r, g, b;
-        if (srgb) {
-            r = srgb8(colour.x, s_srgb);
-            g = srgb8(colour.y, s_srgb);
-            b = srgb8(colour.z, s_srgb);
-        } else {
-            r = unorm8(colour.x);
-            g = unorm8(colour.y);
-            b = unorm8(colour.z);
-        }
-        if (wave == 0 && i0 + uint32_t(lane) < hits) s_tile[pix >> 8][hy][hx] = r | (g << 8) | (b << 16) | 0xff000000u;
+        const uint32_t rgba8 = encode_rgba(colour, srgb, s_srgb);
+        if (wave == 0 && i0 + uint32_t(lane) < hits) s_tile[pix >> 8][hy][hx] = rgba8;
     }
     __syncthreads();
 

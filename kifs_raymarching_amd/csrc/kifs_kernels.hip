@@ -89,17 +89,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
     }
     uint32_t rgba = P.background_rgba;
     if (!culled) {
-        uint32_t r, g, b;
-        if (srgb) {
-            r = srgb8(colour.x, s_srgb);
-            g = srgb8(colour.y, s_srgb);
-            b = srgb8(colour.z, s_srgb);
-        } else {
-            r = unorm8(colour.x);
-            g = unorm8(colour.y);
-            b = unorm8(colour.z);
-        }
-        rgba = r | (g << 8) | (b << 16) | 0xff000000u;  // alpha = 1.0 -> 255
+        rgba = encode_rgba(colour, srgb, s_srgb);
     }
     s_tile[ly][lx] = rgba;
     __syncthreads();
@@ -294,17 +284,8 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             } else {
                 colour = shade_hit<GROUP, PRIM>(P, p);
             }
-            uint32_t r, g, b;
-            if (srgb) {
-                r = srgb8(colour.x, s_srgb);
-                g = srgb8(colour.y, s_srgb);
-                b = srgb8(colour.z, s_srgb);
-            } else {
-                r = unorm8(colour.x);
-                g = unorm8(colour.y);
-                b = unorm8(colour.z);
-            }
-            if ((uint32_t(tid) % LPR) == 0u) s_tile[pix >> 8][hy][hx] = r | (g << 8) | (b << 16) | 0xff000000u;
+            const uint32_t rgba8 = encode_rgba(colour, srgb, s_srgb);
+            if ((uint32_t(tid) % LPR) == 0u) s_tile[pix >> 8][hy][hx] = rgba8;
         }
     }
     __syncthreads();
@@ -328,6 +309,111 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             uint32_t* slot = &P.tile_cost[(tile >> 16) * tiles_x + (tile & 0xffffu)];
             if (batch > 1) atomicMax(slot, cost);  // the batch's views share the table (the sort clears it)
             else *slot = cost;
+        }
+    }
+}
+
+// Shading of a tile's hits with the soft-shadow extension (include/kifs_hip.h), for render_wave_kernel.
+// A hit's secondary march is 1 to shadow_steps estimates long, so 64 of them side by side finish one by one and the
+// wave waits for the longest.  Instead the lanes take the secondary rays from a pool: pass 1 computes every hit's
+// normal and direct term, colours the hits that need no secondary ray and files the others (start point over the
+// pixel's cached direction, which nothing reads any more; pixel id and direct term over the hit list's slots already
+// consumed); pass 2 marches them with per-lane step counters, a lane that finishes its ray taking the next one of the
+// pool; pass 3 encodes.  Every ray's own sequence of operations is soft_shadow()'s: same pixels.
+// hit_pix / hit_val: the hit list, entry i at [CAP - 1 - i] (pixel id, t); dir: the per-pixel direction cache.
+template <int GROUP, int PRIM, uint32_t CAP>
+__device__ __forceinline__ void shade_hits_with_pooled_shadows(const FrameParams& P, uint32_t hits, uint32_t lane, uint8_t* hit_pix,
+                                                               float* hit_val, float (*dir_cache)[CAP], uint32_t (*s_tile)[TILE_W],
+                                                               bool srgb, const float* s_srgb) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const V3 L = normalize(V3{1.0f, 1.0f, 1.0f});
+    const float off = 2.0f * P.epsilon;
+    uint32_t n_sh = 0;  // uniform
+    for (uint32_t i0 = 0; i0 < hits; i0 += 64u) {
+        const bool have = i0 + lane < hits;
+        uint32_t pix = 0;
+        float lit = 0.0f;
+        V3 start{0.0f, 0.0f, 0.0f};
+        if (have) {
+            pix = hit_pix[CAP - 1u - (i0 + lane)];
+            const float t = hit_val[CAP - 1u - (i0 + lane)];
+            const V3 dir = V3{dir_cache[0][pix], dir_cache[1][pix], dir_cache[2][pix]};
+            const V3 p = (t == 0.0f) ? P.origin
+                                     : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                                          fmaf_(t, dir.z, P.origin.z)};
+            const V3 nrm = scene_normal<GROUP, PRIM>(P, p);
+            const float ndl = (nrm.x + nrm.y) + nrm.z;
+            lit = clamp_(ndl, 0.0f, 1.0f);
+            start = V3{fmaf_(off, nrm.x, p.x), fmaf_(off, nrm.y, p.y), fmaf_(off, nrm.z, p.z)};
+        }
+        const bool secondary = have && (lit > 0.0f);
+        const unsigned long long ms = __builtin_amdgcn_ballot_w64(secondary);
+        if (secondary) {  // (slot k <= this hit's own: read above, by every lane, before anything is written)
+            const uint32_t k = n_sh + uint32_t(__builtin_popcountll(ms & below));
+            hit_pix[CAP - 1u - k] = uint8_t(pix);
+            hit_val[CAP - 1u - k] = lit;
+            dir_cache[0][pix] = start.x;
+            dir_cache[1][pix] = start.y;
+            dir_cache[2][pix] = start.z;
+        } else if (have) {  // no direct light: the colour is final
+            const float diffuse = fmaf_(0.9f, lit, 0.1f);
+            const V3 colour{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
+            s_tile[pix >> 5][pix & 31u] = encode_rgba(colour, srgb, s_srgb);
+        }
+        n_sh += uint32_t(__builtin_popcountll(ms));
+    }
+    // pass 2: the pool of secondary rays
+    {
+        uint32_t next = 0;  // uniform: rays handed out so far
+        bool busy = false;
+        uint32_t k = 0;
+        int j = 0;
+        float lit = 0.0f, t = 0.0f, res = 1.0f;
+        V3 start{0.0f, 0.0f, 0.0f};
+        for (;;) {
+            const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+            const uint32_t mine = next + uint32_t(__builtin_popcountll(idle & below));
+            if (!busy && mine < n_sh) {
+                k = mine;
+                const uint32_t pix = hit_pix[CAP - 1u - k];
+                lit = hit_val[CAP - 1u - k];
+                start = V3{dir_cache[0][pix], dir_cache[1][pix], dir_cache[2][pix]};
+                t = P.shadow_t0;
+                res = 1.0f;
+                j = 0;
+                busy = true;
+            }
+            next = min(n_sh, next + uint32_t(__builtin_popcountll(idle)));
+            const unsigned long long lanes = __builtin_amdgcn_ballot_w64(busy);
+            if (lanes == 0ull) break;
+            const V3 q{fmaf_(t, L.x, start.x), fmaf_(t, L.y, start.y), fmaf_(t, L.z, start.z)};
+            const float h = scene_sdf<GROUP, PRIM>(P, q, lanes);
+            if (busy) {
+                bool done;
+                if (h < P.epsilon) {
+                    res = 0.0f;
+                    done = true;
+                } else {
+                    res = min_(res, (P.shadow_k * h) / t);
+                    t = t + h;
+                    done = (t > P.shadow_max_t) || !(j + 1 < P.shadow_steps);
+                    ++j;
+                }
+                if (done) {
+                    hit_val[CAP - 1u - k] = lit * res;  // the attenuated direct term
+                    busy = false;
+                }
+            }
+        }
+    }
+    // pass 3: their colours
+    for (uint32_t k0 = 0; k0 < n_sh; k0 += 64u) {
+        if (k0 + lane < n_sh) {
+            const uint32_t pix = hit_pix[CAP - 1u - (k0 + lane)];
+            const float lit = hit_val[CAP - 1u - (k0 + lane)];
+            const float diffuse = fmaf_(0.9f, lit, 0.1f);
+            const V3 colour{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
+            s_tile[pix >> 5][pix & 31u] = encode_rgba(colour, srgb, s_srgb);
         }
     }
 }
@@ -485,125 +571,9 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
     // ---- shade the hits, 64 at a time
     bool shaded = false;
     if constexpr (GROUP == GROUP_KIFS) {
-        // Soft shadows (the extension of include/kifs_hip.h): a hit's secondary march is 1 to shadow_steps estimates
-        // long, so 64 of them side by side finish one by one and the wave waits for the longest.  Instead the lanes
-        // take the secondary rays from a pool: pass 1 computes every hit's normal and direct term, colours the
-        // hits that need no secondary ray and files the others (start point over the pixel's cached direction, which
-        // nothing reads any more; pixel id and direct term over the hit list's slots already consumed); pass 2
-        // marches them with per-lane step counters, a lane that finishes its ray taking the next one of the pool;
-        // pass 3 encodes.  Every ray's own sequence of operations is soft_shadow()'s: same pixels.
-        if (P.soft_shadow != 0u && P.shadow_steps > 0) {
+        if (P.soft_shadow != 0u && P.shadow_steps > 0) {  // secondary rays from a pool: see the function
             shaded = true;
-            const V3 L = normalize(V3{1.0f, 1.0f, 1.0f});
-            const float off = 2.0f * P.epsilon;
-            uint32_t n_sh = 0;  // uniform
-            for (uint32_t i0 = 0; i0 < hits; i0 += 64u) {
-                const bool have = i0 + lane < hits;
-                uint32_t pix = 0;
-                float lit = 0.0f;
-                V3 start{0.0f, 0.0f, 0.0f};
-                if (have) {
-                    pix = q_pix[1][CAP - 1u - (i0 + lane)];
-                    const float t = q_t[1][CAP - 1u - (i0 + lane)];
-                    const V3 dir = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
-                    const V3 p = (t == 0.0f) ? P.origin
-                                             : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
-                                                  fmaf_(t, dir.z, P.origin.z)};
-                    const V3 nrm = scene_normal<GROUP, PRIM>(P, p);
-                    const float ndl = (nrm.x + nrm.y) + nrm.z;
-                    lit = clamp_(ndl, 0.0f, 1.0f);
-                    start = V3{fmaf_(off, nrm.x, p.x), fmaf_(off, nrm.y, p.y), fmaf_(off, nrm.z, p.z)};
-                }
-                const bool secondary = have && (lit > 0.0f);
-                const unsigned long long ms = __builtin_amdgcn_ballot_w64(secondary);
-                if (secondary) {  // (slot k <= this hit's own: read above, by every lane, before anything is written)
-                    const uint32_t k = n_sh + uint32_t(__builtin_popcountll(ms & below));
-                    q_pix[1][CAP - 1u - k] = uint8_t(pix);
-                    q_t[1][CAP - 1u - k] = lit;
-                    s_dir[0][pix] = start.x;
-                    s_dir[1][pix] = start.y;
-                    s_dir[2][pix] = start.z;
-                } else if (have) {  // no direct light: the colour is final
-                    const float diffuse = fmaf_(0.9f, lit, 0.1f);
-                    const V3 colour{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
-                    uint32_t r, g, b;
-                    if (srgb) {
-                        r = srgb8(colour.x, s_srgb);
-                        g = srgb8(colour.y, s_srgb);
-                        b = srgb8(colour.z, s_srgb);
-                    } else {
-                        r = unorm8(colour.x);
-                        g = unorm8(colour.y);
-                        b = unorm8(colour.z);
-                    }
-                    s_tile[pix >> 5][pix & 31u] = r | (g << 8) | (b << 16) | 0xff000000u;
-                }
-                n_sh += uint32_t(__builtin_popcountll(ms));
-            }
-            // pass 2: the pool of secondary rays
-            {
-                uint32_t next = 0;  // uniform: rays handed out so far
-                bool busy = false;
-                uint32_t k = 0;
-                int j = 0;
-                float lit = 0.0f, t = 0.0f, res = 1.0f;
-                V3 start{0.0f, 0.0f, 0.0f};
-                for (;;) {
-                    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
-                    const uint32_t mine = next + uint32_t(__builtin_popcountll(idle & below));
-                    if (!busy && mine < n_sh) {
-                        k = mine;
-                        const uint32_t pix = q_pix[1][CAP - 1u - k];
-                        lit = q_t[1][CAP - 1u - k];
-                        start = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
-                        t = P.shadow_t0;
-                        res = 1.0f;
-                        j = 0;
-                        busy = true;
-                    }
-                    next = min(n_sh, next + uint32_t(__builtin_popcountll(idle)));
-                    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(busy);
-                    if (lanes == 0ull) break;
-                    const V3 q{fmaf_(t, L.x, start.x), fmaf_(t, L.y, start.y), fmaf_(t, L.z, start.z)};
-                    const float h = scene_sdf<GROUP, PRIM>(P, q, lanes);
-                    if (busy) {
-                        bool done;
-                        if (h < P.epsilon) {
-                            res = 0.0f;
-                            done = true;
-                        } else {
-                            res = min_(res, (P.shadow_k * h) / t);
-                            t = t + h;
-                            done = (t > P.shadow_max_t) || !(j + 1 < P.shadow_steps);
-                            ++j;
-                        }
-                        if (done) {
-                            q_t[1][CAP - 1u - k] = lit * res;  // the attenuated direct term
-                            busy = false;
-                        }
-                    }
-                }
-            }
-            // pass 3: their colours
-            for (uint32_t k0 = 0; k0 < n_sh; k0 += 64u) {
-                if (k0 + lane < n_sh) {
-                    const uint32_t pix = q_pix[1][CAP - 1u - (k0 + lane)];
-                    const float lit = q_t[1][CAP - 1u - (k0 + lane)];
-                    const float diffuse = fmaf_(0.9f, lit, 0.1f);
-                    const V3 colour{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
-                    uint32_t r, g, b;
-                    if (srgb) {
-                        r = srgb8(colour.x, s_srgb);
-                        g = srgb8(colour.y, s_srgb);
-                        b = srgb8(colour.z, s_srgb);
-                    } else {
-                        r = unorm8(colour.x);
-                        g = unorm8(colour.y);
-                        b = unorm8(colour.z);
-                    }
-                    s_tile[pix >> 5][pix & 31u] = r | (g << 8) | (b << 16) | 0xff000000u;
-                }
-            }
+            shade_hits_with_pooled_shadows<GROUP, PRIM, CAP>(P, hits, lane, &q_pix[1][0], &q_t[1][0], s_dir, s_tile, srgb, s_srgb);
         }
     }
     for (uint32_t i0 = 0; !shaded && i0 < hits; i0 += 64u) {
@@ -616,17 +586,7 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
                                      : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
                                           fmaf_(t, dir.z, P.origin.z)};
             const V3 colour = shade_hit<GROUP, PRIM>(P, p);
-            uint32_t r, g, b;
-            if (srgb) {
-                r = srgb8(colour.x, s_srgb);
-                g = srgb8(colour.y, s_srgb);
-                b = srgb8(colour.z, s_srgb);
-            } else {
-                r = unorm8(colour.x);
-                g = unorm8(colour.y);
-                b = unorm8(colour.z);
-            }
-            s_tile[hy][hx] = r | (g << 8) | (b << 16) | 0xff000000u;
+            s_tile[hy][hx] = encode_rgba(colour, srgb, s_srgb);
         }
     }
     __syncthreads();

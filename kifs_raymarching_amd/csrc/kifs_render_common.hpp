@@ -114,6 +114,22 @@ __device__ __forceinline__ void store_background(const FrameParams& P, int tile_
     }
 }
 
+// A linear colour as the frame's RGBA8 pixel: the colour target of the reference (render.rs:72-80, graphics.rs:87-91:
+// sRGB or UNORM format, alpha 1.0), `table` = the sRGB thresholds (LDS or memory).
+__device__ __forceinline__ uint32_t encode_rgba(V3 colour, bool srgb, const float* __restrict__ table) {
+    uint32_t r, g, b;
+    if (srgb) {
+        r = srgb8(colour.x, table);
+        g = srgb8(colour.y, table);
+        b = srgb8(colour.z, table);
+    } else {
+        r = unorm8(colour.x);
+        g = unorm8(colour.y);
+        b = unorm8(colour.z);
+    }
+    return r | (g << 8) | (b << 16) | 0xff000000u;  // alpha = 1.0 -> 255
+}
+
 // the bunny's kernels (kifs_bunny_kernels.hip), launched from launch_render's dispatch in kifs_kernels.hip
 hipError_t launch_bunny_coop(const BatchParams& B, hipStream_t stream);        // four waves per 64 rays, re-queued
 hipError_t launch_bunny_whole_rays(const BatchParams& B, hipStream_t stream);  // four lanes per pixel, start to finish

@@ -236,3 +236,44 @@ def test_bunny_four_waves_per_ray_chunk_equals_oracle(encode, gs, kifs, oracle):
             want = oracle.render(s, c, o, oracle.iters(100, 10, 10), encode=encode)
             assert diff_report(got[k], want)["mismatched_pixels"] == 0, (eps, k)
             assert (want[..., :3] != want[0, 0, :3]).any()
+
+
+@pytest.mark.parametrize("prim,eps,dist", [("SierpinskiTetrahedron", 1e-3, 2.0), ("Torus", 2e-4, 1.3), ("Box", 5e-3, 1.73)])
+def test_pooled_secondary_rays_in_the_wave_kernel_equal_the_oracle(prim, eps, dist, gs, kifs, oracle):
+    """render_wave_kernel shades the hits of a tile with the soft-shadow extension in three passes: normals and direct
+    terms, the secondary rays from a pool (a lane that finishes its ray takes the next one), the colours.  68 views
+    from ON the bounding sphere (radius `dist`: every tile counts as heavy and the launch takes the one-wave-per-tile
+    shape, while the camera stays outside the primitive) of a
+    ragged frame whose tiles hold anything from no hit to 256; UNORM and sRGB; three views against the oracle."""
+    import torch
+    PS = kifs.PrimitiveShape
+    W, H = 424, 300  # 14 x 38 tiles, the last column 8 wide, the last row 4 high
+    screen = kifs.ScreenData(W, H)
+    gui = kifs.GuiData(primitive_shape=getattr(PS, prim), max_iterations=96, epsilon=eps, fractal_color=(230, 180, 60),
+                       background_color=(10, 30, 70))
+    iters = (100, 10, 9)
+    gs.update_screen_data(screen)
+    gs.update_options(gui)
+    gs.set_iters(*iters)
+    gs.set_extensions(soft_shadow=True, shadow_steps=24, shadow_k=8.0, shadow_t0=0.02, shadow_max_t=6.0)
+    ext = oracle.Ext(1, 24, 8.0, 0.02, 6.0)
+    cams = [kifs.CameraData(origin_distance=dist - 0.002 * (k % 3), min_distance=0.5, phi=0.39 * k, theta=0.21 * (k % 9) - 0.8)
+            for k in range(68)]  # (127 200 pixels = 497 tiles' worth x 68 views: past the 32 000 of the one-wave-per-tile shape,
+    shown = []                    #  and past the 64 views that travel in the kernel argument)
+    try:
+        for encode in (1, 0):
+            outs = torch.zeros((len(cams), H, W, 4), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            gs.render_batch_async([outs[i] for i in range(len(cams))], cams, stream=st, encode=encode)
+            st.synchronize()
+            assert gs.debug_last_kernel() == "render_wave_kernel", gs.debug_last_kernel()
+            got = outs.cpu().numpy()
+            for k in (0, 29, 67) if encode else (17,):
+                s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cams[k], gui))
+                want = oracle.render(s, c, o, oracle.iters(*iters), encode=encode, ext=ext)
+                assert diff_report(got[k], want)["mismatched_pixels"] == 0, (prim, encode, k)
+                shown.append(float((want[..., :3] != want[0, 0, :3]).any(-1).mean()))
+    finally:
+        gs.set_extensions(soft_shadow=False)
+    assert max(shown) > 0.05, ("the checked views should show the primitive", shown)
