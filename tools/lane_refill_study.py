@@ -7,7 +7,7 @@ wave-steps:
              or the round does (one chunk left: to the end)
   refill   : 64 lanes, rays handed out in pixel order, a lane takes the next one when its ray ends (list scheduling)
   ideal    : sum of steps / 64
-    python tools/lane_refill_study.py [workload] [round_steps]"""
+    python tools/lane_refill_study.py [workload] [round_steps] [tiles per pool]"""
 import sys
 from pathlib import Path
 
@@ -23,6 +23,7 @@ from kifs_raymarching_amd.configs import WORKLOADS  # noqa: E402
 F = np.float32
 key = sys.argv[1] if len(sys.argv) > 1 else "cfg3_sierpinski_1080p"
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+POOL = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # tiles whose rays share a pool (consecutive tiles of a row)
 w = WORKLOADS[key]
 ub = K.uniform_bytes
 s = NP.Scene(O.from_bytes(O.Screen, ub(w.screen.into_buffer_data())), O.from_bytes(O.Camera, ub(w.camera.into_buffer_data())),
@@ -38,7 +39,7 @@ uvx, uvy = F(2.0) * px / s.h - s.aspect, F(2.0) * py / s.h - F(1.0)
 d = [uvx * s.m[1][k] - uvy * s.m[2][k] - s.m[0][k] for k in range(3)]
 dirv = NP._normalize(d)
 o = s.origin
-B = {0: 1.0, 1: 2.2360680, 2: 1.7320508, 3: 1.3, 4: 2.0, 5: 1.0}[int(s.primitive_id)] if hasattr(s, "primitive_id") else 2.0
+B = {0: 1.0, 1: 2.2360680, 2: 1.7320508, 3: 1.3, 4: 2.0, 5: 1.0}.get(int(s.primitive), 2.0) if int(getattr(s, "group", 0)) == 0 and hasattr(s, "primitive") else 2.0
 Rr = F(B) + s.epsilon
 R2 = F(1.1) * Rr * Rr
 oo = sum(c * c for c in o)
@@ -70,6 +71,7 @@ while live.any() and it < s.max_iterations:
         live[go] = t[go] < s.max_distance
     it += 1
 tile = ((ys.ravel() - y0) // 8) * ((Wc + 31) // 32) + (xs.ravel() - x0) // 32
+tile = tile // POOL
 order = np.lexsort([np.arange(n), tile])
 bounds = np.r_[0, np.nonzero(np.diff(tile[order]))[0] + 1, n]
 tot_rounds = tot_refill = tot_ideal = 0.0
