@@ -313,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     }
 }
 
-// Shading of a tile's hits with the soft-shadow extension (include/kifs_hip.h), for render_wave_kernel.
+// Shading of a tile's hits with the soft-shadow extension (include/kifs_hip.h), for render_wave_kernel (every pipeline).
 // A hit's secondary march is 1 to shadow_steps estimates long, so 64 of them side by side finish one by one and the
 // wave waits for the longest.  Instead the lanes take the secondary rays from a pool: pass 1 computes every hit's
 // normal and direct term, colours the hits that need no secondary ray and files the others (start point over the
@@ -570,11 +570,11 @@ __global__ __launch_bounds__(64) void render_wave_kernel(const BatchParams B) {
 
     // ---- shade the hits, 64 at a time
     bool shaded = false;
-    if constexpr (GROUP == GROUP_KIFS) {
-        if (P.soft_shadow != 0u && P.shadow_steps > 0) {  // secondary rays from a pool: see the function
-            shaded = true;
-            shade_hits_with_pooled_shadows<GROUP, PRIM, CAP>(P, hits, lane, &q_pix[1][0], &q_t[1][0], s_dir, s_tile, srgb, s_srgb);
-        }
+    if (P.soft_shadow != 0u && P.shadow_steps > 0) {  // secondary rays from a pool: see the function
+        shaded = true;
+        // (for the Julia pipeline the PRIM slot is the long-ray loop's variant: its SDF and normal do not depend on it)
+        shade_hits_with_pooled_shadows<GROUP, GROUP == GROUP_JULIA ? 0 : PRIM, CAP>(P, hits, lane, &q_pix[1][0], &q_t[1][0], s_dir, s_tile,
+                                                                                   srgb, s_srgb);
     }
     for (uint32_t i0 = 0; !shaded && i0 < hits; i0 += 64u) {
         if (i0 + lane < hits) {

@@ -238,7 +238,8 @@ def test_bunny_four_waves_per_ray_chunk_equals_oracle(encode, gs, kifs, oracle):
             assert (want[..., :3] != want[0, 0, :3]).any()
 
 
-@pytest.mark.parametrize("prim,eps,dist", [("SierpinskiTetrahedron", 1e-3, 2.0), ("Torus", 2e-4, 1.3), ("Box", 5e-3, 1.73)])
+@pytest.mark.parametrize("prim,eps,dist", [("SierpinskiTetrahedron", 1e-3, 2.0), ("Torus", 2e-4, 1.3), ("Box", 5e-3, 1.73),
+                                           ("julia", 1e-3, 2.0)])
 def test_pooled_secondary_rays_in_the_wave_kernel_equal_the_oracle(prim, eps, dist, gs, kifs, oracle):
     """render_wave_kernel shades the hits of a tile with the soft-shadow extension in three passes: normals and direct
     terms, the secondary rays from a pool (a lane that finishes its ray takes the next one), the colours.  68 views
@@ -249,9 +250,13 @@ def test_pooled_secondary_rays_in_the_wave_kernel_equal_the_oracle(prim, eps, di
     PS = kifs.PrimitiveShape
     W, H = 424, 300  # 14 x 38 tiles, the last column 8 wide, the last row 4 high
     screen = kifs.ScreenData(W, H)
-    gui = kifs.GuiData(primitive_shape=getattr(PS, prim), max_iterations=96, epsilon=eps, fractal_color=(230, 180, 60),
-                       background_color=(10, 30, 70))
-    iters = (100, 10, 9)
+    if prim == "julia":  # the Julia pipeline: its own SDF and analytic normal, the same secondary rays
+        gui = kifs.GuiData(fractal_group=kifs.FractalGroup.JuliaSet, constant=(-0.2, 0.6, 0.2, 0.2), max_iterations=96, epsilon=eps,
+                           fractal_color=(230, 180, 60), background_color=(10, 30, 70))
+    else:
+        gui = kifs.GuiData(primitive_shape=getattr(PS, prim), max_iterations=96, epsilon=eps, fractal_color=(230, 180, 60),
+                           background_color=(10, 30, 70))
+    iters = (12, 10, 9)
     gs.update_screen_data(screen)
     gs.update_options(gui)
     gs.set_iters(*iters)
