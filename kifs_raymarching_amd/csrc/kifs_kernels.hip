@@ -710,3 +710,15 @@ hipError_t launch_render(const BatchParams& B, uint32_t group, uint32_t primitiv
 
 
 }  // namespace kifs
+
+#ifdef KIFS_EVAL_COUNT
+extern "C" int kifs_debug_pow_counts(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(kifs::g_pow_counts), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(kifs::g_pow_counts), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

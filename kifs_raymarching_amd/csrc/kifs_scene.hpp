@@ -67,11 +67,24 @@ KIFS_DEV V4 quat_pow_step(V4 q, float d, float qs, float x, float& dq_factor, bo
 }
 
 // `lanes`: the lanes whose result is used (the others may hold anything and do not force the general path).
+#ifdef KIFS_EVAL_COUNT
+static __device__ unsigned long long g_pow_counts[8];  // [0] wave-level steps, [1] of which repeated with the general functions, [2] lanes at [0]
+#endif
 KIFS_DEV V4 quat_pow_shared(V4 q, float d, float qs, float x, float& dq_factor, bool lanes = true) {
     bool ordinary = false;
     V4 t{};
     const bool power_ok = abs_(x) <= 1.0e5f;  // uniform: |x phi| <= pi |x| stays inside the sin/cos cores' range
     if (__builtin_expect(power_ok, 1)) t = quat_pow_step<false>(q, d, qs, x, dq_factor, ordinary);
+#ifdef KIFS_EVAL_COUNT
+    {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+        if (__lane_id() == uint32_t(__builtin_ctzll(m))) {
+            atomicAdd(&g_pow_counts[0], 1ull);
+            atomicAdd(&g_pow_counts[2], (unsigned long long)__builtin_popcountll(m));
+            if (__builtin_amdgcn_ballot_w64(lanes && !ordinary) != 0ull) atomicAdd(&g_pow_counts[1], 1ull);
+        }
+    }
+#endif
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(lanes && !ordinary) != 0ull, 0))
         t = quat_pow_step<true>(q, d, qs, x, dq_factor, ordinary);
     return t;
