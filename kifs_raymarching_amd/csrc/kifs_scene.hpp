@@ -234,9 +234,14 @@ KIFS_DEV V3 julia_normal(const FrameParams& P, V3 p) {
 }
 
 // ---- generalised Julia -----------------------------------------------------------
-KIFS_DEV float genjulia_sdf(const FrameParams& P, V3 p) {
+// `lanes`: the lanes whose estimate the caller will use.  The others leave at once (their value is unspecified): a ray
+// that has hit sits near the set, where orbits are longest, and stays in its wave until the round ends -- unmasked it
+// made the wave run full-length orbits for a result nobody reads (the Julia loop and the Sierpinski folds mask theirs
+// the same way).
+KIFS_DEV float genjulia_sdf(const FrameParams& P, V3 p, unsigned long long lanes = ~0ull) {
     const float n2 = dot(p, p);
     if (n2 > P.bound_n2) return sqrt_(n2) - 2.0f;  // == length(p) > 2 + epsilon
+    if ((lanes & (1ull << __lane_id())) == 0ull) return 0.0f;
     V4 q{p.x, p.y, p.z, 0.1f};
     float d = quat_ijk2(q);
     float qs = fmaf_(q.x, q.x, d);  // = quat_norm2(q)
@@ -466,7 +471,7 @@ KIFS_DEV V3 kifs_normal(const FrameParams& P, V3 p) {
 template <int GROUP, int PRIM>
 KIFS_DEV float scene_sdf(const FrameParams& P, V3 p, unsigned long long lanes = ~0ull) {
     if constexpr (GROUP == GROUP_JULIA) return julia_sdf(P, p);
-    else if constexpr (GROUP == GROUP_GENJULIA) return genjulia_sdf(P, p);
+    else if constexpr (GROUP == GROUP_GENJULIA) return genjulia_sdf(P, p, lanes);
     else return kifs_sdf<PRIM>(P, p, lanes);
 }
 
