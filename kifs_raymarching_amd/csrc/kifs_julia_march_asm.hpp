@@ -3,7 +3,6 @@
 // KIFS_JULIA_C_OPERANDS defined by the includer.  See the
 // register map and the description there.
     asm volatile(
-        "s_setprio 3\n"   // after the culls only rays that reach the fractal get here: issue them first
         "s_mov_b64 s[84:85], exec\n"
         "s_and_b64 exec, exec, %[lanes]\n"
         "s_mov_b32 s88, 2.0\n"

@@ -750,6 +750,13 @@ KIFS_DEV bool ray_never_inside(const FrameParams& P, V3 dir) {
     return (b <= 0.0f) ? (oo > P.cull_n2) : (c2 > P.cull_n2);
 }
 
+// Issue priority of a wave by the age of its rays (wave-uniform `trips`): see julia_loop.
+KIFS_DEV void march_priority(int trips) {
+    if (trips >= 96) __builtin_amdgcn_s_setprio(3);
+    else if (trips >= 32) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+}
+
 struct JuliaDiag {  // diagnostics of one wave's march (SGPRs)
     int fast_steps = 0, fast_entries = 0, general_steps = 0;
     unsigned long long fast_ticks = 0;
@@ -773,6 +780,12 @@ KIFS_DEV void julia_loop(const FrameParams& P, V3 dir, float& t, V3& p, bool& hi
             // compiler's SGPR handling around the asm block)
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             int outside_steps = 0;  // (a fresh SGPR for the asm block: struct members confuse the allocator)
+            // issue priority by the ray's age: after the culls only rays that reach the fractal get here, and the
+            // longer a ray has marched the more likely it is the one its launch ends with
+            // (levels 1 / 2 / 3 from 0 / 32 / 96 steps; same-box A/B against "3 for all", three runs each, r03: 48 frames per
+            // launch 105.5 -> 106.4 Gpixel/s, 4096^2 x16 64.6 -> 65.3, nothing either way at 8 / 1 per launch; of the other
+            // marks tried 64 / 16 and 48 / 16 were 0.7 % behind, and level 0 for the first round cost 5 % at 8 per launch)
+            march_priority(trips);
             julia_fast_march<SHORT_DIVSQRT, THROUGHPUT>(P, dir, t, p, hit, marching, trips, outside_steps,
                                             limit < P.max_iterations ? limit : P.max_iterations);
             diag.general_steps += outside_steps;
@@ -867,16 +880,25 @@ KIFS_DEV V3 raymarch_julia(const FrameParams& P, V3 dir, bool valid, int& steps)
 
 // `sdf(p, lanes)`: the scene's estimate (lanes = whose value is used); `normal(p)`: its normal.
 // The march loop proper, as julia_loop: until no lane marches or `trips` reaches `limit`.
-template <class Sdf>
+// AGE_PRIORITY: issue priority by the rays' age at entry and at the marks (march_priority), for the one-wave-per-tile
+// throughput kernel, where a round starts here with its rays' step count (same-box A/B, r03: 1080p Sierpinski x48 80.2 ->
+// 81.7 Gpixel/s, the lone 8K frame 1.181 -> 1.142 ms); elsewhere one step up after 32 steps, as before (the graded form
+// cost the lone 1080p Sierpinski frame 3 % and 8 per launch 1 %).
+template <bool AGE_PRIORITY = false, class Sdf>
 KIFS_DEV void generic_loop(const FrameParams& P, V3 dir, float& t, V3& p, bool& hit, bool& marching,
                            int& trips, int& i_final, int limit, Sdf sdf) {
     // Bounding-sphere culls (see raymarch_julia and fill_params): every scene's estimate obeys
     // d(p) >= |p| - B, so a lane outside R = B + epsilon and moving away can never satisfy
     // `d < epsilon`.  Not in heatmap mode.
     const bool cull = (P.is_heatmap == 0u) && (P.cull_n2 > 0.0f);  // wave-uniform
+    if constexpr (AGE_PRIORITY) march_priority(trips);
     while (__builtin_amdgcn_ballot_w64(marching) != 0ull && trips < limit) {
-        // a ray still marching after 32 steps is on the frame's critical path: issue it first
-        if (trips == 32) __builtin_amdgcn_s_setprio(3);
+        if constexpr (AGE_PRIORITY) {
+            if (trips == 32 || trips == 96) march_priority(trips);
+        } else {
+            // a ray still marching after 32 steps is on the frame's critical path: issue it first
+            if (trips == 32) __builtin_amdgcn_s_setprio(3);
+        }
         const bool more = (trips + 1) < P.max_iterations;  // scalar
         if (cull) {  // early ray termination for lanes that are leaving for good
             const bool leaving = (dot(p, p) > P.cull_n2) && (dot(p, dir) > 0.0f);
@@ -958,8 +980,8 @@ KIFS_DEV void march_round(const FrameParams& P, V3 dir, float& t, V3& p, bool& h
         JuliaDiag diag;
         julia_loop<PRIM == 1, THROUGHPUT>(P, dir, t, p, hit, marching, trips, i_final, limit, diag);
     } else {
-        generic_loop(P, dir, t, p, hit, marching, trips, i_final, limit,
-                     [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); });
+        generic_loop<THROUGHPUT>(P, dir, t, p, hit, marching, trips, i_final, limit,
+                                 [&](V3 q, unsigned long long lanes) { return scene_sdf<GROUP, PRIM>(P, q, lanes); });
     }
 }
 
