@@ -38,6 +38,8 @@ constexpr int FEEDBACK_PERIOD_BATCH = 3;              // every n-th batched laun
 constexpr int ROUND_STEPS_JULIA = 16;     // Julia and generalised Julia (4/8/12/16/24/32 -> 62.8/72.2/75.0/76.8/76.8/77.6
                                           // Gpixel/s at 32 frames per launch)                    (tools/sweep_rounds.sh)
 constexpr int ROUND_STEPS_OTHER = 8;      // KIFS scenes; gen-Julia marches under 32 steps        (tools/sweep_rounds.sh)
+constexpr int ROUND_STEPS_KIFS_WAVE = 4;  // KIFS scenes, one wave per tile (2/3/4/5/6/8/12/16 steps: 1080p Sierpinski x48 82.2/83.2/82.7/82.4/81.9/81.8/80.0/78.9
+                                          // Gpixel/s, 8K x8 32.9/33.0/33.2/33.0/32.9/32.8/32.2/31.9; the 256-thread kernel keeps 8: x8 43.2 against 42.8)   (r03)
 constexpr int ROUND_STEPS_LONE_JULIA = 32;  // an uncapped lone Julia frame (4096^2: 0.430 vs 0.445 ms at 16)
 constexpr uint64_t REQUEUE_MIN_WORKGROUPS = 4096u;  // below: no rounds at all (256^2 x 8: 0.038 vs 0.062 ms)
 // shape of the re-queuing path, from profiles/r02/sweep_shapes.jsonl (every shape forced in turn):
@@ -605,6 +607,8 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
                 P.round_steps = rules::ROUND_STEPS_BUNNY_COOP;
         }
         P.group_tiles = shape;
+        if (shape == 0 && kifs_scene && !bunny_scene && P.round_steps == rules::ROUND_STEPS_OTHER && tuning_knob("KIFS_ROUND_STEPS") < 0)
+            P.round_steps = rules::ROUND_STEPS_KIFS_WAVE;
     }
     const bool timed = c->profiling && !c->prof_a.empty() && (c->prof_seen++ % uint64_t(c->prof_every)) == 0;
     const size_t pslot = c->prof_count % (c->prof_a.empty() ? 1 : c->prof_a.size());
