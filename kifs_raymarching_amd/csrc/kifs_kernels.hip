@@ -266,7 +266,129 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     if constexpr (BUNNY) {
         if (hits != 0u && !weights_loaded) bunny_quad_load(W, lane & 3);  // a wave that marched nothing shades too
     }
-    for (uint32_t i0 = 0; i0 < hits; i0 += uint32_t(BLOCK) / LPR) {
+    bool shaded = false;
+    if constexpr (!BUNNY) {
+        // Soft shadows: the secondary rays from a pool, as in render_wave_kernel (shade_hits_with_pooled_shadows), the pool
+        // being the workgroup's: a barrier between reading a chunk of 256 hits and filing its secondary rays over the hit
+        // list's consumed slots, an LDS cursor the four waves draw from.  Same operations per ray: same pixels.
+        if (P.soft_shadow != 0u && P.shadow_steps > 0) {
+            shaded = true;
+            __shared__ uint32_t sh_count, sh_next;
+            constexpr int NPRIM = GROUP == GROUP_JULIA ? 0 : PRIM;  // (the Julia pipeline's PRIM slot is its loop's variant)
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const V3 L = normalize(V3{1.0f, 1.0f, 1.0f});
+            const float off = 2.0f * P.epsilon;
+            if (tid == 0) {
+                sh_count = 0;
+                sh_next = 0;
+            }
+            // pass 1: normals and direct terms; the hits that need no secondary ray get their colour
+            for (uint32_t i0 = 0; i0 < hits; i0 += uint32_t(BLOCK)) {
+                const uint32_t i = i0 + uint32_t(tid);
+                const bool have = i < hits;
+                const uint32_t pix = have ? h_pix[i] : 0u;
+                const float t = have ? h_t[i] : 0.0f;
+                __syncthreads();  // the chunk's entries are read (and the counters cleared) before any slot is filed over
+                float lit = 0.0f;
+                V3 start{0.0f, 0.0f, 0.0f};
+                if (have) {
+                    const V3 dir = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
+                    const V3 p = (t == 0.0f) ? P.origin
+                                             : V3{fmaf_(t, dir.x, P.origin.x), fmaf_(t, dir.y, P.origin.y),
+                                                  fmaf_(t, dir.z, P.origin.z)};
+                    const V3 nrm = scene_normal<GROUP, NPRIM>(P, p);
+                    const float ndl = (nrm.x + nrm.y) + nrm.z;
+                    lit = clamp_(ndl, 0.0f, 1.0f);
+                    start = V3{fmaf_(off, nrm.x, p.x), fmaf_(off, nrm.y, p.y), fmaf_(off, nrm.z, p.z)};
+                }
+                const bool secondary = have && (lit > 0.0f);
+                const unsigned long long ms = __builtin_amdgcn_ballot_w64(secondary);
+                if (ms != 0ull) {
+                    const int first = __builtin_ctzll(ms);
+                    uint32_t base = 0;
+                    if (lane == first) base = atomicAdd(&sh_count, uint32_t(__builtin_popcountll(ms)));
+                    base = uint32_t(__builtin_amdgcn_readlane(int(base), first));
+                    if (secondary) {  // (slot k <= the hits read so far: every one of them is in a register)
+                        const uint32_t k = base + uint32_t(__builtin_popcountll(ms & below));
+                        h_pix[k] = pix;
+                        h_t[k] = lit;
+                        s_dir[0][pix] = start.x;
+                        s_dir[1][pix] = start.y;
+                        s_dir[2][pix] = start.z;
+                    }
+                }
+                if (have && !secondary) {
+                    const float diffuse = fmaf_(0.9f, lit, 0.1f);
+                    const V3 colour{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
+                    s_tile[pix >> 8][(pix >> 5) & 7u][pix & 31u] = encode_rgba(colour, srgb, s_srgb);
+                }
+            }
+            __syncthreads();
+            // pass 2: every lane marches a secondary ray of the pool and takes the next one when it ends
+            {
+                const uint32_t n_sh = sh_count;  // uniform
+                bool busy = false, exhausted = false;
+                uint32_t k = 0;
+                int j = 0;
+                float lit = 0.0f, t = 0.0f, res = 1.0f;
+                V3 start{0.0f, 0.0f, 0.0f};
+                for (;;) {
+                    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+                    if (idle != 0ull && !exhausted) {
+                        const int first = __builtin_ctzll(idle);
+                        uint32_t base = 0;
+                        if (lane == first) base = atomicAdd(&sh_next, uint32_t(__builtin_popcountll(idle)));
+                        base = uint32_t(__builtin_amdgcn_readlane(int(base), first));
+                        const uint32_t mine = base + uint32_t(__builtin_popcountll(idle & below));
+                        if (!busy && mine < n_sh) {
+                            k = mine;
+                            const uint32_t pix = h_pix[k];
+                            lit = h_t[k];
+                            start = V3{s_dir[0][pix], s_dir[1][pix], s_dir[2][pix]};
+                            t = P.shadow_t0;
+                            res = 1.0f;
+                            j = 0;
+                            busy = true;
+                        }
+                        exhausted = base + uint32_t(__builtin_popcountll(idle)) >= n_sh;
+                    }
+                    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(busy);
+                    if (lanes == 0ull) break;
+                    const V3 q{fmaf_(t, L.x, start.x), fmaf_(t, L.y, start.y), fmaf_(t, L.z, start.z)};
+                    const float h = scene_sdf<GROUP, NPRIM>(P, q, lanes);
+                    if (busy) {
+                        bool done;
+                        if (h < P.epsilon) {
+                            res = 0.0f;
+                            done = true;
+                        } else {
+                            res = min_(res, (P.shadow_k * h) / t);
+                            t = t + h;
+                            done = (t > P.shadow_max_t) || !(j + 1 < P.shadow_steps);
+                            ++j;
+                        }
+                        if (done) {
+                            h_t[k] = lit * res;  // the attenuated direct term
+                            busy = false;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // pass 3: their colours
+            const uint32_t n_sh = sh_count;
+            for (uint32_t k0 = 0; k0 < n_sh; k0 += uint32_t(BLOCK)) {
+                const uint32_t k = k0 + uint32_t(tid);
+                if (k < n_sh) {
+                    const uint32_t pix = h_pix[k];
+                    const float diffuse = fmaf_(0.9f, h_t[k], 0.1f);
+                    const V3 colour{diffuse * P.fractal_color.x, diffuse * P.fractal_color.y, diffuse * P.fractal_color.z};
+                    s_tile[pix >> 8][(pix >> 5) & 7u][pix & 31u] = encode_rgba(colour, srgb, s_srgb);
+                }
+            }
+        }
+    }
+    for (uint32_t i0 = 0; !shaded && i0 < hits; i0 += uint32_t(BLOCK) / LPR) {
         const uint32_t i = i0 + uint32_t(tid) / LPR;
         if (i < hits) {
             const uint32_t pix = h_pix[i];

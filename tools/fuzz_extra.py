@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Longer random parity run for the round's new code paths (beyond tests/test_gpu_parity_fuzz.py): batches big enough for
-render_wave_kernel with the soft-shadow extension on (pooled secondary rays) and bunny batches through
-render_bunny_coop_kernel, random primitives / cameras / epsilon / extension parameters, two views per launch against the
+render_wave_kernel and mid-size ones for render_group_kernel with the soft-shadow extension on (pooled secondary rays), and
+bunny batches through render_bunny_coop_kernel, random primitives / cameras / epsilon / extension parameters, two views per launch against the
 oracle.  Prints one line per launch and a summary; exit code 1 on any mismatch.
     python tools/fuzz_extra.py [launches] [seed]"""
 import sys
@@ -42,6 +42,12 @@ for it in range(N):
     d = float(B * rng.uniform(0.97, 1.0))  # on the bounding sphere: every tile counts as heavy
     px_tiles = W * H / 256.0
     views = int(min(120, np.ceil(need / px_tiles) + 1))
+    if kind != "bunny" and rng.integers(0, 3) == 0:
+        # a mid-size launch instead: a bigger frame seen from outside, few views -> render_group_kernel (rays re-queued by a
+        # 256-thread workgroup; with the extension on: its pooled secondary rays)
+        W, H = int(rng.integers(780, 900)), int(rng.integers(480, 560))
+        d = float(B + rng.uniform(0.3, 2.5))
+        views = int(rng.integers(4, 9))
     cams = [K.CameraData(origin_distance=d, min_distance=0.3, phi=float(rng.uniform(0, 6.28)), theta=float(rng.uniform(-1.2, 1.2))) for _ in range(views)]
     shadows = bool(rng.integers(0, 4) != 0)
     ext_args = dict(soft_shadow=shadows, shadow_steps=int(rng.integers(1, 48)), shadow_k=float(rng.uniform(1, 16)),
