@@ -58,7 +58,9 @@ def _variants():
     }
 
 
-def envelope(key):
+def envelope(key, rows=None):
+    """`rows` = (y0, y1): only that band of the frame (the 8K frames take minutes whole; a band through the fractal
+    is what tests/test_parity_envelope.py re-renders)."""
     w = WORKLOADS.get(key) or _variants()[key]
     ub = K.uniform_bytes
     s = O.from_bytes(O.Screen, ub(w.screen.into_buffer_data()))
@@ -66,22 +68,23 @@ def envelope(key):
     o = O.from_bytes(O.Options, ub(w.gui.into_buffer_data()))
     it = O.iters(*w.iters)
     t0 = time.perf_counter()
-    a = O.render(s, c, o, it)
-    t1 = time.perf_counter()
-    _, steps_c, _ = O.render_stats(s, c, o, it)
     H = w.screen.height
-    parts = [NP.render(s, c, o, it, y0=y, y1=min(H, y + BAND_ROWS)) for y in range(0, H, BAND_ROWS)]
+    ya, yb = rows if rows else (0, H)
+    a = O.render(s, c, o, it, y0=ya, y1=yb)
+    t1 = time.perf_counter()
+    _, steps_c, _ = O.render_stats(s, c, o, it, y0=ya, y1=yb)
+    parts = [NP.render(s, c, o, it, y0=y, y1=min(yb, y + BAND_ROWS)) for y in range(ya, yb, BAND_ROWS)]
     b = np.concatenate([p[0] for p in parts], axis=0)
     hit_np = np.concatenate([p[2] for p in parts], axis=0)
     steps_np = np.concatenate([p[1] for p in parts], axis=0)
     t2 = time.perf_counter()
-    bg = a[0, 0].copy()  # the corner is background in every BASELINE view
+    bg = O.render(s, c, o, it, y0=0, y1=1)[0, 0].copy()  # the corner is background in every BASELINE view
     hit_c = (a != bg).any(-1)
     d = np.abs(a.astype(np.int16) - b.astype(np.int16)).max(-1)
     flip = hit_c != hit_np
     n = d.size
     return {
-        "workload": key, "description": w.name, "pixels": int(n),
+        "workload": key + (f"@rows{ya}-{yb}" if rows else ""), "description": w.name, "pixels": int(n),
         "hit_pixels_c_oracle": int(hit_c.sum()), "hit_pixels_numpy": int(hit_np.sum()),
         "differ": float((d > 0).sum() / n), "differ_pixels": int((d > 0).sum()),
         "differ_gt1": float((d > 1).sum() / n), "differ_gt1_pixels": int((d > 1).sum()),
@@ -95,6 +98,15 @@ def envelope(key):
     }
 
 
+def parse_key(k):
+    """'workload' or 'workload@rowsA-B' -> (workload, rows or None)."""
+    if "@rows" in k:
+        k, r = k.split("@rows")
+        a, b = r.split("-")
+        return k, (int(a), int(b))
+    return k, None
+
+
 def main():
     args = sys.argv[1:]
     rnd = "r03"
@@ -106,7 +118,7 @@ def main():
     res = json.loads(out.read_text()) if (out.exists() and args) else []  # named workloads: add to the file
     res = [r for r in res if r["workload"] not in keys]
     for k in keys:
-        r = envelope(k)
+        r = envelope(*parse_key(k))
         print(json.dumps(r), flush=True)
         res.append(r)
         out.write_text(json.dumps(res, indent=1) + "\n")
