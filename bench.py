@@ -414,7 +414,6 @@ def one_process(args):
         last = base + args.steps - 1
         got = frames[last % 2]
         ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev0)
-        torch.cuda.synchronize()  # (the fill runs on torch's stream, the renders below on the context's own)
         with K.GraphicState(0, screen_data=w.screen, camera_data=w.camera, gui_data=w.gui) as g1:
             g1.set_iters(*w.iters)
             if w.extensions:
@@ -798,7 +797,6 @@ def main():
         last = settle_steps + args.warmup + args.steps - 1
         if rank == 0:
             ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
-            torch.cuda.synchronize()  # (the fill runs on torch's stream, the renders below on the context's own)
 
             def single(frame_index):
                 gs.set_raw_uniforms(camera=cameras(frame_index, 1, args.camera)[0])

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define KIFS_ABI_VERSION 3
+#define KIFS_ABI_VERSION 4
 
 /* ---- uniform images (data.rs:17-49) --------------------------------------- */
 
@@ -155,7 +155,12 @@ int kifs_set_extensions(kifs_ctx* ctx, const KifsExtensions* ext);
  *
  * The library launches on non-blocking streams (its own, or the caller's `hip_stream`): work the caller has
  * pending on OTHER streams for the destination (a fill, a previous consumer) is not ordered before the render
- * unless the caller orders it, as with any asynchronous HIP work.
+ * unless the caller orders it, as with any asynchronous HIP work.  kifs_order_after does that in one call: the
+ * context's NEXT work on `hip_stream` (NULL = the context's own stream, the one kifs_render uses) runs after
+ * everything `producer_stream` (a hipStream_t of the context's device; NULL = the legacy default stream) holds
+ * when the call is made -- an event recorded there and waited for on the launch stream; nothing blocks the host;
+ * the same stream twice is a no-op.  (The reference has one queue and copies on every update,
+ * util/uniform.rs:23-35, so the question does not arise there.)
  *
  * kifs_render: `out` may be a device pointer of the context's device or a host
  * pointer; returns once `out` holds the pixels.
@@ -166,6 +171,7 @@ int kifs_render(kifs_ctx* ctx, uint8_t* out_rgba8, size_t pitch_bytes, int y0, i
                 int encode);
 int kifs_render_async(kifs_ctx* ctx, void* hip_stream, uint8_t* dev_out_rgba8,
                       size_t pitch_bytes, int y0, int y1, int encode);
+int kifs_order_after(kifs_ctx* ctx, void* hip_stream, void* producer_stream);
 
 /* A batch of frames in one launch: frame i is rendered with cameras[i] (the context's screen,
  * options, iteration counts and extensions; the context's own camera is neither used nor
@@ -335,6 +341,10 @@ int kifs_multi_render_batch_async(kifs_multi* m, int count, const KifsCameraUnif
 int kifs_multi_wait(kifs_multi* m, uint64_t step);
 int kifs_multi_wait_all(kifs_multi* m);
 int kifs_multi_stream_wait(kifs_multi* m, uint64_t step, void* hip_stream);
+/* The counterpart of kifs_order_after for the frames a kifs_multi writes on its ROOT device: whatever the object
+ * enqueues there from now on (the root's renders, the fill / erase and the scatter of the gather) runs after
+ * everything `producer_stream` (a stream of the root device; NULL = the legacy default stream) holds now. */
+int kifs_multi_order_after(kifs_multi* m, void* producer_stream);
 int kifs_multi_render_batch(kifs_multi* m, int count, const KifsCameraUniform* cameras, uint8_t* dev_frames,
                             size_t frame_pitch, size_t frame_stride, int encode);
 /* What the gather moved since creation (or the last call with reset != 0): steps completed, records received

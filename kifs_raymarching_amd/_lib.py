@@ -85,6 +85,8 @@ SIGNATURES = {
     "kifs_render": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "kifs_render_async": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                     C.c_int]),
+    "kifs_order_after": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
+    "kifs_multi_order_after": (C.c_int, [_ctx, C.c_void_p]),
     "kifs_render_batch_async": (C.c_int, [_ctx, C.c_void_p, C.c_int, _P(CameraUniform),
                                           _P(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "kifs_band_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
@@ -182,6 +184,15 @@ def _share_hip_runtime_with_torch():
 
 def _load():
     _share_hip_runtime_with_torch()
+    import os
+    variant = os.environ.get("KIFS_LIB_VARIANT")
+    if variant and os.environ.get("KIFS_TUNING") == "1":
+        # a sweep's prebuilt variant (tools/sweep_*_variants.sh), loaded from where it lies: the library in the tree
+        # and its stamp stay what the sources say.  Said on stderr, so that no measurement can pass for the tree's.
+        import sys
+        print(f"kifs: loading the library VARIANT {variant} (KIFS_LIB_VARIANT under KIFS_TUNING=1), not the tree's",
+              file=sys.stderr)
+        return _bind(C.CDLL(variant))
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library has not been built "
@@ -194,14 +205,33 @@ def _load():
     kb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kb)
     if kb.STAMP.exists() and not kb.is_current():
-        raise ImportError(f"{LIB_PATH} was built from other sources than the ones in csrc/ (hash mismatch): rebuild it "
+        src, _ = kb.recorded()
+        why = ("was built from other sources than the ones in csrc/" if src != kb.source_hash()
+               else "is not the file the build produced (replaced after the build?)")
+        raise ImportError(f"{LIB_PATH} {why} (hash mismatch): rebuild it "
                           "(python -c 'import __graft_entry__ as g; g.build()')")
-    lib = C.CDLL(str(LIB_PATH))
+    return _bind(C.CDLL(str(LIB_PATH)))
+
+
+def source_hash_of_loaded_library() -> str:
+    """The source hash recorded when the loaded library was built ("" for a variant or an unstamped library):
+    what profiles/pmc_traffic.json entries are tied to (bench.py)."""
+    import importlib.util
+    import os
+    if os.environ.get("KIFS_LIB_VARIANT") and os.environ.get("KIFS_TUNING") == "1":
+        return ""
+    spec = importlib.util.spec_from_file_location("_kifs_build_check", PKG_DIR / "build.py")
+    kb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kb)
+    return kb.recorded()[0]
+
+
+def _bind(lib):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.kifs_abi_version() != 3:
+    if lib.kifs_abi_version() != 4:
         raise ImportError("libkifs_hip.so: ABI version mismatch")
     return lib
 

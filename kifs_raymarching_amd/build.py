@@ -21,12 +21,31 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def library_hash() -> str:
+    return hashlib.sha256(LIB.read_bytes()).hexdigest() if LIB.exists() else ""
+
+
+def write_stamp() -> None:
+    """Two lines: the hash of the sources the library was built from, and the hash of the library file itself --
+    so that a library copied over the built one (a sweep's variant) is noticed as well as an edited source."""
+    STAMP.write_text(source_hash() + "\n" + library_hash() + "\n")
+
+
+def recorded() -> tuple:
+    """(source hash, library hash) of the stamp; ("", "") without one."""
+    if not STAMP.exists():
+        return "", ""
+    lines = STAMP.read_text().split()
+    return (lines[0] if lines else ""), (lines[1] if len(lines) > 1 else "")
+
+
 def is_current() -> bool:
-    return LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == source_hash()
+    src, lib = recorded()
+    return LIB.exists() and src == source_hash() and lib == library_hash()
 
 
 def build(force: bool = False) -> None:
     if not force and is_current():
         return
     subprocess.run(["make", "-C", str(CSRC), "-B"], check=True)
-    STAMP.write_text(source_hash() + "\n")
+    write_stamp()

@@ -70,6 +70,7 @@ kifs_ctx* kifs_create(int device_ordinal, int* status) {
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev_start) == hipSuccess &&
               hipEventCreate(&c->ev_stop) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&c->d_srgb), sizeof c->h_srgb) == hipSuccess &&
               hipMemcpy(c->d_srgb, table, sizeof c->h_srgb, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {
@@ -109,6 +110,7 @@ void kifs_destroy(kifs_ctx* c) {
     if (c->d_srgb) (void)hipFree(c->d_srgb);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -153,6 +155,19 @@ int kifs_set_extensions(kifs_ctx* c, const KifsExtensions* ext) {
     if (ext->soft_shadow && ext->shadow_steps < 0) return KIFS_ERR_BAD_ARG;
     c->ext = *ext;
     return KIFS_OK;
+}
+
+int kifs_order_after(kifs_ctx* c, void* hip_stream, void* producer_stream) {
+    if (!c) return KIFS_ERR_BAD_ARG;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t producer = static_cast<hipStream_t>(producer_stream);  // NULL: the legacy default stream
+    if (s == producer) return KIFS_OK;  // one stream: already in order
+    DeviceGuard g(c->device);
+    if (!g.ok) return KIFS_ERR_RUNTIME;
+    // (one event serves every call: a wait captures the record that precedes it, a later record does not move it)
+    return hip_ok(hipEventRecord(c->ev_order, producer), "record(order_after)") &&
+                   hip_ok(hipStreamWaitEvent(s, c->ev_order, 0), "wait(order_after)")
+               ? KIFS_OK : KIFS_ERR_RUNTIME;
 }
 
 int kifs_render_async(kifs_ctx* c, void* hip_stream, uint8_t* dev_out, size_t pitch, int y0,

@@ -53,6 +53,7 @@ struct kifs_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // tile-order sorts run here, beside the renders
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_order = nullptr;  // kifs_order_after: recorded on the producer's stream, waited for on the launch stream
     float* d_srgb = nullptr;       // 256 thresholds
     uint8_t* d_scratch = nullptr;  // frame staging for host destinations
     size_t scratch_bytes = 0;

@@ -124,6 +124,7 @@ struct StepSlot {
     size_t pitch = 0, stride = 0;
     uint32_t background = 0;
     bool background_known = false; // `frames` hold the background outside the records of `part` (sparse, flushed)
+    bool overwritten = false;      // something else wrote into `frames` since this step was submitted
     std::vector<PeerPart> part;
     std::vector<int> peer_stripes; // every stripe that is not the root's, ascending
     hipEvent_t rendered = nullptr; // root render stream: the root's own rows are in the frames
@@ -192,18 +193,34 @@ int ensure_transport(kifs_multi* m) {
     if (m->transport != KIFS_TRANSPORT_AUTO) return KIFS_OK;
     const int n = int(m->dev.size());
     int want = m->transport_wanted;
-    if (want == KIFS_TRANSPORT_AUTO) want = (n >= 2 && all_distinct(m->dev)) ? KIFS_TRANSPORT_RCCL : KIFS_TRANSPORT_COPY;
+    const bool automatic = want == KIFS_TRANSPORT_AUTO;
+    if (automatic) want = (n >= 2 && all_distinct(m->dev)) ? KIFS_TRANSPORT_RCCL : KIFS_TRANSPORT_COPY;
     if (want == KIFS_TRANSPORT_RCCL) {
-        if (!all_distinct(m->dev)) return KIFS_ERR_COMM;  // ncclCommInitAll refuses a device listed twice
-        const RcclApi* a = rccl();
-        if (!a) return KIFS_ERR_COMM;
-        m->comm.assign(size_t(n), nullptr);
-        if (!nccl_ok(a->CommInitAll(m->comm.data(), n, m->dev.data()), "ncclCommInitAll")) {
-            m->comm.clear();
-            return KIFS_ERR_COMM;
+        // An explicit KIFS_TRANSPORT_RCCL that cannot be had is an error; AUTO falls back to peer copies (a node
+        // without a loadable librccl, or whose ncclCommInitAll fails, still gathers) and says so under KIFS_DEBUG
+        // and in stats.transport.
+        auto give_up = [&](const char* why) {
+            if (!automatic) return int(KIFS_ERR_COMM);
+            if (std::getenv("KIFS_DEBUG")) std::fprintf(stderr, "kifs: %s; KIFS_TRANSPORT_AUTO falls back to peer copies\n", why);
+            want = KIFS_TRANSPORT_COPY;
+            return int(KIFS_OK);
+        };
+        int st = KIFS_OK;
+        const RcclApi* a = nullptr;
+        if (!all_distinct(m->dev)) st = give_up("a device is listed twice (ncclCommInitAll refuses that)");
+        else if (!(a = rccl())) st = give_up("librccl could not be opened");
+        else {
+            m->comm.assign(size_t(n), nullptr);
+            if (!nccl_ok(a->CommInitAll(m->comm.data(), n, m->dev.data()), "ncclCommInitAll")) {
+                m->comm.clear();
+                (void)hipGetLastError();
+                st = give_up("ncclCommInitAll failed");
+            } else {
+                m->stats.rccl_version = a->version;
+                m->stats.comm_ranks = n;
+            }
         }
-        m->stats.rccl_version = a->version;
-        m->stats.comm_ranks = n;
+        if (st != KIFS_OK) return st;
     }
     m->transport = want;
     m->stats.transport = want;
@@ -282,6 +299,7 @@ int flush_slot(kifs_multi* m, StepSlot& sl) {
     std::vector<uint8_t*> dst(size_t(n), nullptr);
     std::vector<size_t> bytes(size_t(n), 0);
     std::vector<hipEvent_t> ready(size_t(n), nullptr);
+    uint64_t records = 0, tiles = 0, payload = 0;
     for (int i = 1; i < n; ++i) {
         PeerPart& p = sl.part[size_t(i)];
         p.n_records = 0;
@@ -295,8 +313,8 @@ int flush_slot(kifs_multi* m, StepSlot& sl) {
             p.n_records = *p.h_count;
             p.payload_bytes = size_t(p.n_records) * KIFS_SPARSE_RECORD_BYTES;
             src[size_t(i)] = p.records;
-            m->stats.records_received += p.n_records;
-            m->stats.tiles_covered += capacity;
+            records += p.n_records;
+            tiles += capacity;
         } else {
             p.payload_bytes = size_t(sl.count) * size_t(p.rows) * row_bytes;
             src[size_t(i)] = p.shard;
@@ -304,10 +322,13 @@ int flush_slot(kifs_multi* m, StepSlot& sl) {
         dst[size_t(i)] = p.recv;
         bytes[size_t(i)] = p.payload_bytes;
         ready[size_t(i)] = p.packed;
-        m->stats.bytes_received += p.payload_bytes;
+        payload += p.payload_bytes;
     }
     int st = transfer_to_root(m, src, dst, bytes, ready, false);
     if (st != KIFS_OK) return st;
+    m->stats.records_received += records;  // (counted once the transfers are posted: a failed flush that is
+    m->stats.tiles_covered += tiles;       // tried again must not count twice)
+    m->stats.bytes_received += payload;
     {   // the root moves what arrived to its rows of the frames
         DeviceGuard g(m->dev[0]);
         kifs_ctx* root = m->ctx[0];
@@ -328,7 +349,7 @@ int flush_slot(kifs_multi* m, StepSlot& sl) {
         if (!hip_ok(hipEventRecord(sl.gathered, gstream), "record(gathered)")) return KIFS_ERR_RUNTIME;
     }
     sl.flushed = true;
-    sl.background_known = sparse;
+    sl.background_known = sparse && !sl.overwritten;
     if (m->have_pending && m->pending == sl.step) m->have_pending = false;
     return KIFS_OK;
 }
@@ -355,6 +376,26 @@ int drain(kifs_multi* m) {
         if (st != KIFS_OK) return st;
     }
     return KIFS_OK;
+}
+
+// [frames, end) of what a step writes
+inline const uint8_t* frames_end(const uint8_t* frames, int count, size_t pitch, size_t stride, int width, int height) {
+    return frames + size_t(count - 1) * stride + size_t(height - 1) * pitch + size_t(width) * 4;
+}
+
+// Something is about to write [lo, hi) on the root: a slot whose frames overlap that range no longer knows that they
+// hold the background outside its records -- its next submission must fill, whatever KIFS_MULTI_FRAMES_UNTOUCHED
+// says (the other slot rendering into the same buffer, a lone kifs_multi_render into it, buffers that overlap).
+void forget_background(kifs_multi* m, const StepSlot* except, const uint8_t* lo, const uint8_t* hi) {
+    for (StepSlot& o : m->slot) {
+        if (&o == except || !o.frames || o.count < 1) continue;
+        const uint8_t* olo = o.frames;
+        const uint8_t* ohi = frames_end(o.frames, o.count, o.pitch, o.stride, o.width, o.height);
+        if (lo < ohi && olo < hi) {
+            o.background_known = false;
+            o.overwritten = true;  // (also for a flush of that slot's step that is still to come)
+        }
+    }
 }
 
 void free_slot(kifs_multi* m, StepSlot& sl) {
@@ -536,6 +577,7 @@ int kifs_multi_render(kifs_multi* m, uint8_t* out, size_t pitch, int encode) {
     st = multi_partition(m, h);
     if (st != KIFS_OK) return st;
     const int n = int(m->ctx.size());
+    forget_background(m, nullptr, out, out + size_t(h - 1) * pitch + row_bytes);  // (a host pointer overlaps nothing)
     // the frame the shards are collected into: the caller's buffer if it is root-device memory
     uint8_t* frame = out;
     size_t fpitch = pitch;
@@ -668,6 +710,9 @@ int kifs_multi_render_batch_async(kifs_multi* m, int count, const KifsCameraUnif
                             sl.frames == dev_frames && sl.pitch == frame_pitch && sl.stride == frame_stride &&
                             sl.count == count && sl.encode == encode && sl.background == background &&
                             sl.width == w && sl.height == h && sl.gather == KIFS_GATHER_SPARSE;
+    // (erase_only looked at this slot's own record of the buffer; the OTHER slot's record of any buffer this step
+    // writes into is void from here on)
+    forget_background(m, &sl, dev_frames, frames_end(dev_frames, count, frame_pitch, frame_stride, w, h));
     if (sl.part.size() != size_t(n)) sl.part.resize(size_t(n));
     {
         DeviceGuard g(m->dev[0]);
@@ -704,77 +749,100 @@ int kifs_multi_render_batch_async(kifs_multi* m, int count, const KifsCameraUnif
     sl.used = true;
     sl.flushed = false;
     sl.background_known = false;
+    sl.overwritten = false;
     sl.step = step;
     sl.count = count; sl.encode = encode; sl.gather = m->gather; sl.width = w; sl.height = h;
     sl.frames = dev_frames; sl.pitch = frame_pitch; sl.stride = frame_stride; sl.background = background;
     // ---- every device: one launch for its shard of all the step's frames, then its payload
     const size_t tiles_x = size_t((w + kifs::TILE_W - 1) / kifs::TILE_W);
     m->outs_scratch.resize(size_t(count));
-    for (int i = 0; i < n; ++i) {
-        kifs_ctx* c = m->ctx[size_t(i)];
-        PeerPart& p = sl.part[size_t(i)];
-        p.stripes = m->stripes[size_t(i)];
-        p.rows = m->rows[size_t(i)];
-        p.n_records = 0;
-        p.payload_bytes = 0;
-        DeviceGuard g(m->dev[size_t(i)]);
-        if (!g.ok) return KIFS_ERR_RUNTIME;
-        m->shard_ms[size_t(i)] = -1.0;
-        if (p.stripes.empty()) {
-            if (i == 0 && !hip_ok(hipEventRecord(sl.rendered, c->stream), "record(rendered)")) return KIFS_ERR_RUNTIME;
-            continue;
-        }
-        const size_t shard_stride = size_t(p.rows) * row_bytes;
-        if (i == 0) {
-            for (int f = 0; f < count; ++f) m->outs_scratch[size_t(f)] = dev_frames + size_t(f) * frame_stride;
-        } else {
-            const size_t need = shard_stride * size_t(count);
-            const size_t capacity = size_t(count) * p.stripes.size() * tiles_x;
-            if (!make_event(p.packed)) return KIFS_ERR_RUNTIME;
-            // buffers that grow are replaced while nothing reads them: the slot's previous step is complete
-            if (!grow(p.shard, p.shard_bytes, need, "hipMalloc(step shards)")) return KIFS_ERR_RUNTIME;
+    auto launch_all = [&]() -> int {
+        for (int i = 0; i < n; ++i) {
+            kifs_ctx* c = m->ctx[size_t(i)];
+            PeerPart& p = sl.part[size_t(i)];
+            p.stripes = m->stripes[size_t(i)];
+            p.rows = m->rows[size_t(i)];
+            p.n_records = 0;
+            p.payload_bytes = 0;
+            DeviceGuard g(m->dev[size_t(i)]);
+            if (!g.ok) return KIFS_ERR_RUNTIME;
+            m->shard_ms[size_t(i)] = -1.0;
+            if (p.stripes.empty()) {
+                if (i == 0 && !hip_ok(hipEventRecord(sl.rendered, c->stream), "record(rendered)")) return KIFS_ERR_RUNTIME;
+                continue;
+            }
+            const size_t shard_stride = size_t(p.rows) * row_bytes;
+            if (i == 0) {
+                for (int f = 0; f < count; ++f) m->outs_scratch[size_t(f)] = dev_frames + size_t(f) * frame_stride;
+            } else {
+                const size_t need = shard_stride * size_t(count);
+                const size_t capacity = size_t(count) * p.stripes.size() * tiles_x;
+                if (!make_event(p.packed)) return KIFS_ERR_RUNTIME;
+                // buffers that grow are replaced while nothing reads them: the slot's previous step is complete
+                if (!grow(p.shard, p.shard_bytes, need, "hipMalloc(step shards)")) return KIFS_ERR_RUNTIME;
+                if (sparse) {
+                    if (!grow(p.records, p.records_bytes, capacity * KIFS_SPARSE_RECORD_BYTES, "hipMalloc(step records)")) return KIFS_ERR_RUNTIME;
+                    if (!p.d_count && !hip_ok(hipMalloc(reinterpret_cast<void**>(&p.d_count), sizeof(uint32_t)), "hipMalloc(record count)"))
+                        return KIFS_ERR_RUNTIME;
+                    if (!p.h_count && !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&p.h_count), sizeof(uint32_t), hipHostMallocDefault),
+                                              "hipHostMalloc(record count)"))
+                        return KIFS_ERR_RUNTIME;
+                }
+                {
+                    DeviceGuard gr(m->dev[0]);
+                    if (!grow(p.recv, p.recv_bytes, sparse ? capacity * KIFS_SPARSE_RECORD_BYTES : need, "hipMalloc(step receive)"))
+                        return KIFS_ERR_RUNTIME;
+                }
+                // (the payload of the slot's previous step has left these buffers: that step was completed above, and
+                // its completion includes the root's scatter, which follows the transfer in the gather stream)
+                for (int f = 0; f < count; ++f) m->outs_scratch[size_t(f)] = p.shard + size_t(f) * shard_stride;
+            }
+            if (!hip_ok(hipEventRecord(m->ev0[size_t(i)], c->stream), "record(launch start)")) return KIFS_ERR_RUNTIME;
+            st = enqueue_batch(c, c->stream, count, cameras, m->outs_scratch.data(), i == 0 ? frame_pitch : row_bytes, 0, h, encode,
+                               p.stripes.data(), int(p.stripes.size()), i == 0 ? 1 : 0);
+            if (st != KIFS_OK) return st;
+            if (!hip_ok(hipEventRecord(m->ev1[size_t(i)], c->stream), "record(launch stop)")) return KIFS_ERR_RUNTIME;
+            if (i == 0) {
+                if (!hip_ok(hipEventRecord(sl.rendered, c->stream), "record(rendered)")) return KIFS_ERR_RUNTIME;
+                continue;
+            }
             if (sparse) {
-                if (!grow(p.records, p.records_bytes, capacity * KIFS_SPARSE_RECORD_BYTES, "hipMalloc(step records)")) return KIFS_ERR_RUNTIME;
-                if (!p.d_count && !hip_ok(hipMalloc(reinterpret_cast<void**>(&p.d_count), sizeof(uint32_t)), "hipMalloc(record count)"))
-                    return KIFS_ERR_RUNTIME;
-                if (!p.h_count && !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&p.h_count), sizeof(uint32_t), hipHostMallocDefault),
-                                          "hipHostMalloc(record count)"))
-                    return KIFS_ERR_RUNTIME;
-            }
-            {
-                DeviceGuard gr(m->dev[0]);
-                if (!grow(p.recv, p.recv_bytes, sparse ? capacity * KIFS_SPARSE_RECORD_BYTES : need, "hipMalloc(step receive)"))
+                const RowTable* rows = row_table(c, p.stripes.data(), int(p.stripes.size()), h);
+                if (!rows) return KIFS_ERR_RUNTIME;
+                if (!hip_ok(hipMemsetAsync(p.d_count, 0, sizeof(uint32_t), c->stream), "memset(record count)") ||
+                    !hip_ok(kifs::launch_pack_sparse(p.shard, row_bytes, shard_stride, rows->d_rows, int(p.stripes.size()), count, w, h,
+                                                     background, reinterpret_cast<uint32_t*>(p.records), p.d_count, c->stream),
+                            "pack_sparse_kernel launch") ||
+                    !hip_ok(hipMemcpyAsync(p.h_count, p.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream), "copy(record count)"))
                     return KIFS_ERR_RUNTIME;
             }
-            // (the payload of the slot's previous step has left these buffers: that step was completed above, and
-            // its completion includes the root's scatter, which follows the transfer in the gather stream)
-            for (int f = 0; f < count; ++f) m->outs_scratch[size_t(f)] = p.shard + size_t(f) * shard_stride;
+            if (!hip_ok(hipEventRecord(p.packed, c->stream), "record(packed)")) return KIFS_ERR_RUNTIME;
         }
-        if (!hip_ok(hipEventRecord(m->ev0[size_t(i)], c->stream), "record(launch start)")) return KIFS_ERR_RUNTIME;
-        st = enqueue_batch(c, c->stream, count, cameras, m->outs_scratch.data(), i == 0 ? frame_pitch : row_bytes, 0, h, encode,
-                           p.stripes.data(), int(p.stripes.size()), i == 0 ? 1 : 0);
-        if (st != KIFS_OK) return st;
-        if (!hip_ok(hipEventRecord(m->ev1[size_t(i)], c->stream), "record(launch stop)")) return KIFS_ERR_RUNTIME;
-        if (i == 0) {
-            if (!hip_ok(hipEventRecord(sl.rendered, c->stream), "record(rendered)")) return KIFS_ERR_RUNTIME;
-            continue;
-        }
-        if (sparse) {
-            const RowTable* rows = row_table(c, p.stripes.data(), int(p.stripes.size()), h);
-            if (!rows) return KIFS_ERR_RUNTIME;
-            if (!hip_ok(hipMemsetAsync(p.d_count, 0, sizeof(uint32_t), c->stream), "memset(record count)") ||
-                !hip_ok(kifs::launch_pack_sparse(p.shard, row_bytes, shard_stride, rows->d_rows, int(p.stripes.size()), count, w, h,
-                                                 background, reinterpret_cast<uint32_t*>(p.records), p.d_count, c->stream),
-                        "pack_sparse_kernel launch") ||
-                !hip_ok(hipMemcpyAsync(p.h_count, p.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream), "copy(record count)"))
-                return KIFS_ERR_RUNTIME;
-        }
-        if (!hip_ok(hipEventRecord(p.packed, c->stream), "record(packed)")) return KIFS_ERR_RUNTIME;
-    }
-    if (n == 1) {
+        return KIFS_OK;
+    };
+    st = launch_all();
+    if (st == KIFS_OK && n == 1) {
         DeviceGuard g(m->dev[0]);
-        if (!hip_ok(hipEventRecord(sl.gathered, gstream), "record(gathered)")) return KIFS_ERR_RUNTIME;
-        sl.flushed = true;
+        if (hip_ok(hipEventRecord(sl.gathered, gstream), "record(gathered)")) sl.flushed = true;
+        else st = KIFS_ERR_RUNTIME;
+    }
+    if (st != KIFS_OK) {
+        // A step that was only partly enqueued is no step: whatever was launched is waited for (it writes into the
+        // caller's frames and the slot's buffers), the slot is free again, the step number is not used up -- a later
+        // submit, wait or destroy must not flush record counts and events of a launch that never happened.
+        for (int i = 0; i < n; ++i) {
+            DeviceGuard g(m->dev[size_t(i)]);
+            (void)hipStreamSynchronize(m->ctx[size_t(i)]->stream);
+        }
+        {
+            DeviceGuard g(m->dev[0]);
+            (void)hipStreamSynchronize(gstream);
+        }
+        (void)hipGetLastError();
+        sl.used = false;
+        sl.flushed = false;
+        sl.background_known = false;
+        return st;
     }
     m->next_step = step + 1;
     if (step_out) *step_out = step;
@@ -820,6 +888,19 @@ int kifs_multi_stream_wait(kifs_multi* m, uint64_t step, void* hip_stream) {
     return hip_ok(hipStreamWaitEvent(s, sl.rendered, 0), "stream wait(rendered)") &&
                    hip_ok(hipStreamWaitEvent(s, sl.gathered, 0), "stream wait(gathered)")
                ? KIFS_OK : KIFS_ERR_RUNTIME;
+}
+
+int kifs_multi_order_after(kifs_multi* m, void* producer_stream) {
+    if (!m) return KIFS_ERR_BAD_ARG;
+    int st = ensure_streams(m);
+    if (st != KIFS_OK) return st;
+    // the root's render stream first (kifs_order_after records the context's ordering event on the producer's
+    // stream), then the same event for the gather stream
+    if ((st = kifs_order_after(m->ctx[0], nullptr, producer_stream)) != KIFS_OK) return st;
+    if (m->ctx[0]->stream == static_cast<hipStream_t>(producer_stream)) return KIFS_OK;
+    DeviceGuard g(m->dev[0]);
+    return hip_ok(hipStreamWaitEvent(m->comm_stream[0], m->ctx[0]->ev_order, 0), "wait(multi order_after)") ? KIFS_OK
+                                                                                                          : KIFS_ERR_RUNTIME;
 }
 
 int kifs_multi_render_batch(kifs_multi* m, int count, const KifsCameraUniform* cameras, uint8_t* dev_frames,

@@ -164,6 +164,16 @@ def _device_pointer(obj):
     return int(obj)
 
 
+def _producer_stream(dest):
+    """hipStream_t of torch's CURRENT stream on the device of `dest` (0 = the legacy default stream) when `dest` is
+    a torch CUDA tensor -- the stream whatever produced the tensor (torch.zeros' fill kernel, a consumer's last read)
+    was enqueued on, as far as this wrapper can know; None for raw pointers and host arrays."""
+    if not getattr(dest, "is_cuda", False):
+        return None
+    import torch
+    return int(torch.cuda.current_stream(dest.device).cuda_stream)
+
+
 class GraphicState:
     """render/graphics.rs:25-37.  Owns one library context bound to one HIP device."""
 
@@ -279,6 +289,18 @@ class GraphicState:
         check(lib.kifs_set_extensions(self._ctx, C.byref(e)), "set_extensions")
 
     # -- render (graphics.rs:310-325) -----------------------------------------------------
+    def _order_after_producer(self, dest, launch_stream):
+        """The wrapper's stream rule for torch destinations: the library launches on non-blocking streams, which
+        nothing orders after torch's current stream -- where the destination's fill, or its previous reader, sits.
+        Every render entry point below therefore makes its launch stream (None = the context's) wait for an event
+        recorded on torch's current stream of the destination's device (kifs_order_after: two HIP calls, nothing
+        blocks the host; the same stream on both sides is a no-op).  A C caller does the same with kifs_order_after
+        or orders its streams itself (include/kifs_hip.h); the reference has one queue (util/uniform.rs:23-35)."""
+        producer = _producer_stream(dest)
+        if producer is None or (launch_stream and producer == launch_stream):
+            return
+        check(lib.kifs_order_after(self._ctx, launch_stream, producer or None), "order_after")
+
     def render(self, out=None, y0: int = 0, y1: int = None, encode: int = ENCODE_SRGB,
                pitch_bytes: int = None):
         """Synchronous frame.  `out` None -> returns a (rows, W, 4) uint8 ndarray; an
@@ -295,6 +317,7 @@ class GraphicState:
             ptr = out.ctypes.data
         else:
             ptr = _device_pointer(out)
+            self._order_after_producer(out, None)
         check(lib.kifs_render(self._ctx, ptr, pitch, y0, y1, encode), "render")
         return out
 
@@ -311,6 +334,7 @@ class GraphicState:
                 # default stream has handle 0 and would silently end up there
                 raise ValueError("render_async: pass a non-default torch.cuda.Stream "
                                  "(the null stream handle selects the context's stream)")
+        self._order_after_producer(out, stream)
         check(lib.kifs_render_async(self._ctx, stream, _device_pointer(out), pitch, y0, y1,
                                     encode), "render_async")
 
@@ -331,6 +355,7 @@ class GraphicState:
         n = len(outs)
         cams = camera_array(cameras)
         ptrs = outs.array if isinstance(outs, DevicePointers) else (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
+        self._order_after_producer(outs[0], stream)
         check(lib.kifs_render_batch_async(self._ctx, stream, n, cams, ptrs, pitch, y0, y1, encode),
               "render_batch_async")
 
@@ -369,6 +394,7 @@ class GraphicState:
                 outs.checked_bytes = need
         ptrs = outs.array if isinstance(outs, DevicePointers) else (C.c_void_p * n)(*[_device_pointer(o) for o in outs])
         st = _stripe_array(stripes)
+        self._order_after_producer(outs[0], stream)
         check(lib.kifs_render_shard_async(self._ctx, stream, n, cams, ptrs, pitch, st, len(st),
                                           1 if in_place else 0, encode), "render_shard_async")
 
@@ -391,6 +417,7 @@ class GraphicState:
             if not stream:
                 raise ValueError("unpack_shard_async: pass a non-default torch.cuda.Stream")
         st = _stripe_array(stripes)
+        self._order_after_producer(frames, stream)
         check(lib.kifs_unpack_shard_async(self._ctx, stream, count, _device_pointer(frames), w * 4, h * w * 4,
                                           _device_pointer(shards), w * 4, rows * w * 4, st, len(st)),
               "unpack_shard_async")
@@ -429,7 +456,9 @@ class GraphicState:
                                            or not host_n_records.is_pinned()):
             raise ValueError("pack_sparse_async: host_n_records is one 32-bit integer in pinned host memory")
         st = _stripe_array(stripes)
-        check(lib.kifs_pack_sparse_async(self._ctx, self._stream_handle(stream, "pack_sparse_async"), count,
+        stream = self._stream_handle(stream, "pack_sparse_async")
+        self._order_after_producer(records, stream)
+        check(lib.kifs_pack_sparse_async(self._ctx, stream, count,
                                          _device_pointer(shards), w * 4, rows * w * 4, st, len(st), encode,
                                          _device_pointer(records), int(records.shape[0]), _device_pointer(n_records),
                                          _device_pointer(host_n_records) if host_n_records is not None else None),
@@ -450,13 +479,15 @@ class GraphicState:
                 or not records.is_contiguous() or records.element_size() != 1)):
             raise ValueError("unpack_sparse_async: n_records records of 1040 bytes, at most one per tile of the shards")
         st = _stripe_array(stripes)
+        stream = self._stream_handle(stream, "erase_sparse_async" if _erase_encode is not None else "unpack_sparse_async")
+        self._order_after_producer(frames, stream)
         if _erase_encode is not None:
-            check(lib.kifs_erase_sparse_async(self._ctx, self._stream_handle(stream, "erase_sparse_async"), count,
+            check(lib.kifs_erase_sparse_async(self._ctx, stream, count,
                                               _device_pointer(frames), w * 4, h * w * 4,
                                               _device_pointer(records) if n_records else None, n_records, st, len(st),
                                               _erase_encode), "erase_sparse_async")
             return
-        check(lib.kifs_unpack_sparse_async(self._ctx, self._stream_handle(stream, "unpack_sparse_async"), count,
+        check(lib.kifs_unpack_sparse_async(self._ctx, stream, count,
                                            _device_pointer(frames), w * 4, h * w * 4,
                                            _device_pointer(records) if n_records else None, n_records, st, len(st)),
               "unpack_sparse_async")
@@ -467,7 +498,9 @@ class GraphicState:
         if frames.dim() != 4 or tuple(frames.shape[1:]) != (h, w, 4) or not frames.is_contiguous() or frames.element_size() != 1:
             raise ValueError(f"fill_shard_async: frames (count, {h}, {w}, 4) uint8, contiguous")
         st = _stripe_array(stripes)
-        check(lib.kifs_fill_shard_async(self._ctx, self._stream_handle(stream, "fill_shard_async"), int(frames.shape[0]),
+        stream = self._stream_handle(stream, "fill_shard_async")
+        self._order_after_producer(frames, stream)
+        check(lib.kifs_fill_shard_async(self._ctx, stream, int(frames.shape[0]),
                                         _device_pointer(frames), w * 4, h * w * 4, st, len(st), encode),
               "fill_shard_async")
 
@@ -600,8 +633,16 @@ class MultiGraphicState:
         if isinstance(out, np.ndarray):
             _check_host_destination(out, h, w, pitch_bytes or w * 4)
         ptr = out.ctypes.data if isinstance(out, np.ndarray) else _device_pointer(out)
+        self._order_after_producer(out)
         check(lib.kifs_multi_render(self._m, ptr, pitch_bytes or w * 4, encode), "multi render")
         return out
+
+    def _order_after_producer(self, dest):
+        """GraphicState._order_after_producer for the root device's streams (kifs_multi_order_after): what this object
+        enqueues on the root from now on follows torch's current stream there."""
+        producer = _producer_stream(dest)
+        if producer is not None:
+            check(lib.kifs_multi_order_after(self._m, producer or None), "multi order_after")
 
     # ---- batches of frames, gathered on the first device (kifs_multi_render_batch_async) ----------------
     def set_extensions(self, soft_shadow=False, shadow_steps=0, shadow_k=0.0, shadow_t0=0.0, shadow_max_t=0.0):
@@ -632,6 +673,7 @@ class MultiGraphicState:
         Returns the step number for wait() / stream_wait().  untouched=True: `frames` is the buffer passed two
         steps ago and nothing else wrote to it since (KIFS_MULTI_FRAMES_UNTOUCHED)."""
         n, cams, ptr, pitch, stride = self._frames_args(frames, cameras)
+        self._order_after_producer(frames)
         step = C.c_uint64(0)
         check(lib.kifs_multi_render_batch_async(self._m, n, cams, ptr, pitch, stride, encode,
                                                 _lib.MULTI_FRAMES_UNTOUCHED if untouched else 0, C.byref(step)),
@@ -640,6 +682,7 @@ class MultiGraphicState:
 
     def render_batch(self, frames, cameras, encode: int = ENCODE_SRGB):
         n, cams, ptr, pitch, stride = self._frames_args(frames, cameras)
+        self._order_after_producer(frames)
         check(lib.kifs_multi_render_batch(self._m, n, cams, ptr, pitch, stride, encode), "multi render_batch")
         return frames
 

@@ -55,7 +55,7 @@ def test_header_compiles_as_c_and_sizes_match(tmp_path):
 
 def test_strerror_and_version(kifs):
     from kifs_raymarching_amd._lib import lib
-    assert lib.kifs_abi_version() == 3
+    assert lib.kifs_abi_version() == 4
     assert lib.kifs_strerror(0) == b"ok"
     msgs = {lib.kifs_strerror(i) for i in range(8)}
     assert len(msgs) == 8 and lib.kifs_strerror(99) == b"unknown status"

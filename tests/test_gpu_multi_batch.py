@@ -118,6 +118,75 @@ def test_untouched_flag_is_ignored_when_anything_differs(kifs):
         assert torch.equal(a.cpu(), want) and torch.equal(b.cpu(), want) and torch.equal(other.cpu(), want)
 
 
+def test_one_buffer_for_every_step_with_the_untouched_flag(kifs):
+    """ONE buffer handed back on every step (waited for in between, as the contract asks) with the
+    untouched flag set.  The slot of step k - 2 only knows the records IT scattered; step k - 1 (the other slot)
+    scattered its own into the same buffer since, so an erase under step k - 2's records alone would leave step
+    k - 1's tiles standing wherever step k is background.  Poses differ per step so that the tiles do."""
+    import torch
+    gui, iters, dist = _scenes(kifs)["julia"]
+    screen = kifs.ScreenData(320, 200)
+    B = 4
+    with kifs.MultiGraphicState([0, 0, 0], screen, kifs.CameraData(), gui, iters=iters) as mg:
+        a = torch.zeros((B, 200, 320, 4), dtype=torch.uint8, device="cuda:0")
+        for k in range(5):
+            poses = [kifs.CameraData(origin_distance=dist + 0.8 * (k % 3), phi=1.1 * k + 0.4 * i, theta=0.3 * (-1) ** k)
+                     for i in range(B)]
+            mg.wait(mg.render_batch_async(a, poses, untouched=True))
+            assert torch.equal(a.cpu(), _single_frames(kifs, screen, gui, iters, poses)), k
+        # ... and a lone kifs_multi_render into the first frame of the buffer between two steps
+        mg.set_camera(kifs.CameraData(origin_distance=3.0, phi=2.0, theta=-0.5))
+        mg.render(out=a[0])
+        poses = _cameras(kifs, B, dist + 1.5, first=3)
+        mg.wait(mg.render_batch_async(a, poses, untouched=True))
+        assert torch.equal(a.cpu(), _single_frames(kifs, screen, gui, iters, poses))
+        # overlapping buffers: frames 1..4 of a five-frame allocation after frames 0..3 of it
+        big = torch.zeros((B + 1, 200, 320, 4), dtype=torch.uint8, device="cuda:0")
+        for k, view in enumerate((big[:B], big[1:], big[:B], big[1:])):
+            poses = _cameras(kifs, B, dist + 0.5 * k, first=7 * k)
+            mg.wait(mg.render_batch_async(view, poses, untouched=True))
+            assert torch.equal(view.cpu(), _single_frames(kifs, screen, gui, iters, poses)), k
+
+
+def test_the_wrapper_orders_its_launches_after_torchs_current_stream(kifs):
+    """VERDICT r03 item 5 / ADVICE r03: the library's streams are non-blocking, so nothing orders a render after the
+    fill kernel torch.zeros / torch.full left on torch's current stream -- except the wrapper, which makes the launch
+    stream wait for an event recorded there (kifs_order_after, kifs_multi_order_after).  A long fill is queued in
+    front of the destination's own fill, on the default stream and on a side stream; a frame rendered 'at once' must
+    survive both."""
+    import torch
+    gui, iters, dist = _scenes(kifs)["box"]
+    screen = kifs.ScreenData(256, 128)
+    cams = _cameras(kifs, 3, dist)
+    want = _single_frames(kifs, screen, gui, iters, cams)
+    side = torch.cuda.Stream()
+    with kifs.GraphicState(0, screen_data=screen, camera_data=cams[0], gui_data=gui) as gs, \
+            kifs.MultiGraphicState([0, 0], screen, cams[0], gui, iters=iters) as mg:
+        gs.set_iters(*iters)
+        for where in (None, side, None, side):
+            with torch.cuda.stream(where) if where is not None else torch.cuda.stream(torch.cuda.default_stream()):
+                ballast = torch.full((1 << 29,), 3, dtype=torch.uint8, device="cuda:0")  # 0.5 GB: tenths of a millisecond
+                lone = torch.full((128, 256, 4), 77, dtype=torch.uint8, device="cuda:0")
+                batch = [torch.full((128, 256, 4), 78, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+                frames = torch.full((3, 128, 256, 4), 79, dtype=torch.uint8, device="cuda:0")
+                gs.render(out=lone)                      # the context's stream, synchronous
+                gs.render_batch_async(batch, cams)       # the context's stream
+                mg.render_batch(frames, cams)            # the root's render and gather streams
+                launch = torch.cuda.Stream()
+                again = torch.full((128, 256, 4), 80, dtype=torch.uint8, device="cuda:0")
+                gs.set_camera(cams[1])
+                gs.render_async(again, stream=launch)    # a caller's stream
+                gs.set_camera(cams[0])
+            gs.synchronize()
+            launch.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(lone.cpu(), want[0])
+            assert all(torch.equal(batch[i].cpu(), want[i]) for i in range(3))
+            assert torch.equal(frames.cpu(), want)
+            assert torch.equal(again.cpu(), want[1])
+            del ballast
+
+
 def test_stream_wait_orders_a_consumer_stream(kifs):
     import torch
     gui, iters, dist = _scenes(kifs)["julia"]
