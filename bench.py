@@ -115,6 +115,11 @@ def parse():
                     help="N = 1: a step is the workload's WHOLE orbit (max(frames, 120) poses, every frame resident in HBM) "
                          "in launches of --frames-per-launch frames")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--calibration-note", default=None, help=argparse.SUPPRESS)  # set by self_launch()'s second attempt
+    ap.add_argument("--dist-at-one", action="store_true",
+                    help="--gpus 1 only: run the N > 1 code path with a world of one rank -- process group (backend as given), "
+                         "its barrier / all_reduce / all_gather, the CPU side group, the sharded pipeline with no peers -- the "
+                         "half of a multi-GPU run that a one-GPU box can prove (tests/test_gpu_bench.py)")
     ap.add_argument("--cfg5-secondary", default="auto", choices=["auto", "off"],
                     help="headline workload at N = 1: 'auto' also times BASELINE config 5 as it is named -- the whole 120-frame "
                          "7680x4320 Sierpinski orbit, every frame resident (15.9 GB) -- in a child process under a time limit "
@@ -122,45 +127,171 @@ def parse():
     return ap.parse_args()
 
 
+# ---- stages: where a run is, said on stderr by every rank, with a deadline ------------------------
+# The first multi-GPU run is also the first contact of this code with RCCL between two devices: a rank that
+# stalls in a collective must cost a clear message and a non-zero exit within minutes, not the driver's whole
+# time limit.  Every rank announces each stage it enters (one stderr line: rank, stage, deadline) and a
+# watchdog thread in the rank gives up -- os._exit(3), after saying where -- when a stage outlives its
+# deadline; under torch.distributed.run that ends the job, under self_launch() the parent (which follows the
+# same lines through the children's stderr) stops the other ranks and reports every rank's last stage.
+_T0 = time.time()
+_STAGE = {"name": "start", "since": _T0, "deadline": 600.0}
+STAGE_DEADLINES = (  # first prefix that matches; seconds
+    ("import", 420.0),            # the first `import torch` of a fresh box pages the image in: 1-2 minutes
+    ("init process group", 300.0),
+    ("gloo side group", 120.0),
+    ("calibration", 150.0),       # per candidate: ten steps of the real pipeline
+    ("settle", 180.0), ("warmup", 180.0), ("check", 300.0), ("reduce", 120.0),
+    ("one-process child", 220.0), ("cfg5", 200.0), ("cpu baseline", 180.0), ("secondary", 240.0),
+)
+
+
+def _deadline_scale():
+    try:
+        return max(0.01, float(os.environ.get("KIFS_BENCH_DEADLINE_SCALE", "1")))
+    except ValueError:
+        return 1.0
+
+
+def stage(name, deadline_s=None):
+    """Announces the stage this rank enters.  KIFS_BENCH_STALL=<stage prefix>:<rank or *> makes that rank sleep
+    there (the rehearsal of a hung collective: tests/test_bench_stages.py, tools/rehearse_multi.sh)."""
+    if deadline_s is None:
+        deadline_s = next((d for p, d in STAGE_DEADLINES if name.startswith(p)), 240.0)
+    deadline_s *= _deadline_scale()
+    now = time.time()
+    _STAGE.update(name=name, since=now, deadline=deadline_s)
+    rank = os.environ.get("RANK", "0")
+    print(f"bench.py[rank {rank}] stage: {name} | deadline {deadline_s:.0f} s | t=+{now - _T0:.1f} s", file=sys.stderr, flush=True)
+    stall = os.environ.get("KIFS_BENCH_STALL", "")
+    if stall and ":" in stall:
+        prefix, who = stall.rsplit(":", 1)
+        if name.startswith(prefix) and who in ("*", rank):
+            time.sleep(1e6)
+
+
+def start_watchdog():
+    import threading
+    if os.environ.get("KIFS_BENCH_NO_RANK_WATCHDOG") == "1":  # tests of self_launch()'s own backstop
+        return
+
+    def watch():
+        while True:
+            time.sleep(0.25)
+            st = dict(_STAGE)
+            if st["name"] == "done":
+                return
+            waited = time.time() - st["since"]
+            if waited > st["deadline"]:
+                rank = os.environ.get("RANK", "0")
+                print(f"bench.py[rank {rank}] STALLED in stage '{st['name']}' for {waited:.0f} s (deadline "
+                      f"{st['deadline']:.0f} s): giving up", file=sys.stderr, flush=True)
+                os._exit(3)
+    threading.Thread(target=watch, daemon=True, name="bench-stage-watchdog").start()
+
+
 # ---- N > 1 without a launcher: start the ranks ------------------------------------------------
-def self_launch(args):
+def self_launch(args, attempt=0, extra=()):
     """Starts one fresh child process per GPU and relays rank 0's JSON line.  Runs BEFORE anything
     in this process touches the GPU (no torch import, no HIP call): a process that has initialised
-    the GPU must never be replaced or forked into ranks."""
+    the GPU must never be replaced or forked into ranks.  The children's stderr passes through this process, which
+    follows their stage lines: a rank that exits non-zero, or a stage that outlives its deadline by more than the
+    grace the rank's own watchdog gets, stops exactly the children started here; the last stage of every rank is
+    printed and the exit code is non-zero.  Nothing is ever launched a second time."""
+    import tempfile
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    import tempfile
     procs = []
+    last = {}  # rank -> (stage, entered at, deadline)
+    lock = threading.Lock()
+
+    def follow(r, pipe):
+        for raw in iter(pipe.readline, b""):
+            line = raw.decode("utf-8", "replace")
+            sys.stderr.write(line)
+            sys.stderr.flush()
+            tag = f"bench.py[rank {r}] stage: "
+            if line.startswith(tag):
+                parts = line[len(tag):].split(" | ")
+                try:
+                    dl = float(parts[1].split()[1])
+                except (IndexError, ValueError):
+                    dl = 240.0
+                with lock:
+                    last[r] = (parts[0].strip(), time.time(), dl)
+        pipe.close()
+
+    def report(why):
+        with lock:
+            where = {r: f"'{v[0]}' for {time.time() - v[1]:.0f} s (deadline {v[2]:.0f} s)" for r, v in sorted(last.items())}
+        print(f"bench.py: {why}; last stage of every rank: " + json.dumps(where), file=sys.stderr, flush=True)
+
     with tempfile.TemporaryFile("w+") as out0:
+        readers = []
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
-                                          stdout=out0 if r == 0 else sys.stderr))
-        # a rank that dies leaves the others waiting in a collective: stop them (exactly the
-        # children started above) instead of waiting for a communicator time-out
-        failed = False
+            p = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:] + list(extra), env=env,
+                                 stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
+            procs.append(p)
+            last[r] = ("(not started)", time.time(), 420.0 * _deadline_scale())
+            t = threading.Thread(target=follow, args=(r, p.stderr), daemon=True)
+            t.start()
+            readers.append(t)
+
+        def stop_children():
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+
+        failed = None
+        # the rank's own watchdog fires first and says where; this is the backstop for a wedged interpreter
+        grace = max(1.0, 20.0 * min(1.0, _deadline_scale()))
         while any(p.poll() is None for p in procs):
             if any(p.returncode not in (None, 0) for p in procs):
-                failed = True
-                for p in procs:
-                    if p.poll() is None:
-                        p.terminate()
-                t_end = time.time() + 10
-                for p in procs:
-                    try:
-                        p.wait(timeout=max(0.1, t_end - time.time()))
-                    except subprocess.TimeoutExpired:
-                        p.kill()
+                # a rank that dies leaves the others waiting in a collective: stop them (exactly the
+                # children started above) instead of waiting for a communicator time-out
+                failed = f"a rank failed (exit codes {[p.returncode for p in procs]})"
+                stop_children()
+                break
+            now = time.time()
+            with lock:
+                late = [(r, v) for r, v in last.items() if procs[r].poll() is None and now - v[1] > v[2] + grace]
+            if late:
+                r, v = late[0]
+                failed = f"rank {r} stalled in stage '{v[0]}' for {now - v[1]:.0f} s (deadline {v[2]:.0f} s)"
+                stop_children()
                 break
             time.sleep(0.05)
-        failed = failed or any(p.returncode != 0 for p in procs)
+        for t in readers:
+            t.join(timeout=5)
+        if failed is None and any(p.returncode != 0 for p in procs):
+            failed = f"a rank failed (exit codes {[p.returncode for p in procs]})"
         out0.seek(0)
         sys.stdout.write(out0.read())
         sys.stdout.flush()
     if failed:
-        sys.exit(f"bench.py: a rank failed (exit codes {[p.returncode for p in procs]})")
+        report(failed)
+        with lock:
+            stalled_in_calibration = any(v[0].startswith("calibration") for v in last.values())
+        if stalled_in_calibration and attempt == 0 and args.root_weight == "auto":
+            # The trial of rank 0's share is an optimisation, not the measurement: if it is what failed, the job runs once
+            # more WITHOUT it -- fresh children of this process, which has never touched a GPU -- at 1:1, and the line says
+            # so (config.root_weight_calibration).  Anything that fails there fails the run.
+            print("bench.py: the calibration of rank 0's share failed; starting the ranks once more with --root-weight 1:1",
+                  file=sys.stderr, flush=True)
+            return self_launch(args, attempt=1, extra=["--root-weight", "1:1", "--calibration-note",
+                                                       "first attempt: " + failed])
+        sys.exit(f"bench.py: {failed} (exit codes {[p.returncode for p in procs]})")
 
 
 # ---- CPU-side figures ----------------------------------------------------------------------------
@@ -352,6 +483,7 @@ def one_process(args):
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the render path has no CPU fallback")
     N = args.gpus
+    stage("one-process: contexts on every device")
     have = torch.cuda.device_count()
     devices = [0] * N if args.share_device else list(range(N))
     if not args.share_device and have < N:
@@ -393,13 +525,21 @@ def one_process(args):
     step_ms = max(0.05, fps * W * H / N / 60.0e6)
     settle = min(400, int(-(-max(0, args.settle_ms) // step_ms)))
     settle += settle % 2
-    for k in range(settle + args.warmup):
+    stage(f"one-process: first step (transport set-up: ncclCommInitAll over {len(set(devices))} device(s))")
+    step(0)
+    mg.wait_all()
+    seen = mg.stats()
+    if seen["transport"] == "rccl" and seen["comm_ranks"] != N:
+        sys.exit(f"bench.py: the library's communicator has {seen['comm_ranks']} ranks, --gpus says {N}")
+    stage(f"one-process: settle + warmup ({settle + args.warmup} steps)")
+    for k in range(1, settle + args.warmup):
         step(k)
     mg.wait_all()
     for d in set(devices):
         torch.cuda.synchronize(d)
     mg.stats(reset=True)
     base = settle + args.warmup
+    stage(f"one-process: timed ({args.steps} steps)", deadline_s=120.0 + 0.5 * args.steps)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(base + k)
@@ -411,6 +551,7 @@ def one_process(args):
     shards = mg.shards()
     check = None
     if not args.no_check:
+        stage("one-process: check")
         last = base + args.steps - 1
         got = frames[last % 2]
         ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev0)
@@ -477,11 +618,15 @@ def main():
     if args.gpus > 1 and args.host == "one-process":
         # one process for the whole node: under a launcher every rank but the first has nothing to do
         if int(os.environ.get("RANK", "0")) == 0:
+            start_watchdog()
             one_process(args)
+            _STAGE["name"] = "done"
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
 
+    start_watchdog()
+    stage("import")
     import torch
     import torch.distributed as dist
 
@@ -492,18 +637,29 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    args.gpus = world
+    if world != args.gpus:
+        # the driver's command names --gpus N and launches N ranks: anything else is a launch that lost ranks (or a
+        # stale environment), and a line computed from it would be quoted for the wrong N
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong number of GPUs")
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the render path has no CPU fallback")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.dist_at_one
+    if dist_on:
+        stage(f"init process group ({args.backend})")
+        if "MASTER_ADDR" not in os.environ:  # --dist-at-one without a launcher
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     key = args.workload or HEADLINE
     w = WORKLOADS[key]
@@ -542,20 +698,61 @@ def main():
             camera_arrays[key_] = K.camera_array([poses[(first + i) % len(poses)] for i in range(n)])
         return camera_arrays[key_]
 
+    class Scene:
+        """What a pipeline renders: a workload, its context on this rank's device and its orbit's camera images."""
+
+        def __init__(self, key_, w_, g_, cameras_):
+            self.key, self.w, self.gs, self.cameras = key_, w_, g_, cameras_
+            self.W, self.H = w_.screen.width, w_.screen.height
+
+    main_scene = Scene(key, w, gs, cameras)
+
+    def other_scene(key_):
+        """A second workload beside the headline's (its own context; the same streams)."""
+        w_ = WORKLOADS[key_]
+        g_ = K.GraphicState(local_rank, screen_data=w_.screen, camera_data=w_.camera, gui_data=w_.gui)
+        g_.set_iters(*w_.iters)
+        if w_.extensions:
+            g_.set_extensions(**w_.extensions)
+        images = [orbit_camera(w_, i).into_buffer_data() for i in range(max(w_.frames, 120))]
+        cache = {}
+
+        def cams(first, n, mode):
+            k_ = (first % len(images), n)
+            if k_ not in cache:
+                if len(cache) > 16:
+                    cache.clear()
+                cache[k_] = K.camera_array([images[(first + i) % len(images)] for i in range(n)])
+            return cache[k_]
+        return Scene(key_, w_, g_, cams)
+
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
 
-    def run(pipeline, step, steps, warmup):
+    def max_over_ranks(x):
+        """MAX of a host float over the ranks (on the device for RCCL, on the CPU for gloo)."""
+        if not dist_on:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run(pipeline, step, steps, warmup, announce=False, scene=None):
         """warmup + timed loop of `step(k)`; returns wall seconds and the per-launch kernel times
         (HIP event pairs recorded by the library on the launch stream around the render kernel)."""
+        gss_ = [scene.gs] if scene else gss
+        if announce:
+            stage(f"warmup ({warmup} steps)")
         for k in range(warmup):
             step(k)
         pipeline.wait_all()
         torch.cuda.synchronize()
-        for g in gss:
+        for g in gss_:
             # every 4th launch: an event pair costs a few microseconds (short runs: every 2nd)
             g.set_profiling(4 if steps >= 40 else 2)
+        if announce:
+            stage(f"timed ({steps} steps)", deadline_s=120.0 + 0.5 * steps)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -565,16 +762,16 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
-        reads = [g.profile_read() for g in gss]
-        for g in gss:
+        reads = [g.profile_read() for g in gss_]
+        for g in gss_:
             g.set_profiling(0)
         n = sum(r[0] for r in reads)
         return {"elapsed": elapsed, "launches_timed": n,
                 "kernel_ms": sum(r[0] * r[1] for r in reads) / max(n, 1),
                 "kernel_ms_min": min((r[2] for r in reads if r[0] > 0), default=0.0),
                 "kernel_ms_max": max((r[3] for r in reads if r[0] > 0), default=0.0),
-                "round_steps": gss[0].debug_last_round_steps(), "group_tiles": gss[0].debug_last_group_tiles(),
-                "kernel": gss[0].debug_last_kernel()}
+                "round_steps": gss_[0].debug_last_round_steps(), "group_tiles": gss_[0].debug_last_group_tiles(),
+                "kernel": gss_[0].debug_last_kernel()}
 
     def whole_frames(frames_per_launch, camera_mode, deliver=False):
         """Every rank renders whole frames: step k, rank r: frames (k N + r) b .. + b - 1 (at N = 1
@@ -625,9 +822,11 @@ def main():
                                               cameras(a, m_, "orbit"), stream=streams[0], y0=0, y1=H, encode=args.encode)
         return Resident, step
 
-    def row_shards(frames_per_step, camera_mode, contiguous, root_weight=(1, 1)):
+    def row_shards(frames_per_step, camera_mode, contiguous, root_weight=(1, 1), scene=None):
         """The north star's path: every rank renders its row shard of the step's frames (launches of
-        at most MAX_BATCH frames) and rank 0 gathers them."""
+        at most MAX_BATCH frames) and rank 0 gathers them.  `scene`: another workload than the headline's."""
+        sc = scene or main_scene
+        W, H, gs, cameras = sc.W, sc.H, sc.gs, sc.cameras  # (shadow the headline's: everything below is the scene's)
         weights = None
         if not contiguous and root_weight[0] != root_weight[1]:
             weights = [root_weight[0]] + [root_weight[1]] * (world - 1)
@@ -707,10 +906,25 @@ def main():
         links (--gather dense) rank 0 wants several times a peer's share; with sparse shards about the same."""
         candidates = ([(1, 1), (3, 4), (4, 3), (2, 3), (3, 2), (1, 2), (2, 1)] if args.gather == "sparse"
                       else [(1, 1), (2, 1), (3, 1), (4, 1), (6, 1), (8, 1), (12, 1), (16, 1)])
-        on = device if args.backend == "nccl" else "cpu"
         trial = {}
+        note = None
+        t_begin = time.perf_counter()
+        budget_s = 90.0 * _deadline_scale()  # the whole calibration; a candidate takes well under a second
         for i, cand in enumerate(candidates):
-            sf, step = row_shards(frames_per_step, args.camera, contiguous=False, root_weight=cand)
+            stage(f"calibration {i + 1}/{len(candidates)} (rank 0 : peer = {cand[0]} : {cand[1]})")
+            error = None
+            try:  # building a candidate's pipeline allocates (rank 0: two buffers of the step's frames) and talks to nobody
+                sf, step = row_shards(frames_per_step, args.camera, contiguous=False, root_weight=cand)
+            except Exception as e:
+                error, sf, step = repr(e)[:200], None, None
+            # every rank agrees whether everybody could build it BEFORE anybody enters a collective of the trial: a rank
+            # that cannot must not leave the others waiting for it (a collective that hangs later is the watchdog's)
+            if max_over_ranks(1.0 if error else 0.0) > 0.0:
+                note = f"candidate {cand[0]}:{cand[1]} could not be set up on a rank" + (f" (here: {error})" if error else "")
+                print(f"bench.py[rank {rank}] calibration: {note}; falling back to 1:1", file=sys.stderr, flush=True)
+                trial = {}
+                del sf, step
+                break
             # (the first trial also brings the device's clocks up: it gets the settle phase's worth of steps)
             warm = 4 + (settle_count(frames_per_step) if i == 0 else 0)
             for k in range(warm):
@@ -724,30 +938,38 @@ def main():
             sf.wait_all()
             torch.cuda.synchronize()
             barrier()
-            t = torch.tensor([(time.perf_counter() - t0) / 6], dtype=torch.float64, device=on)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            trial[cand] = float(t.item())
+            seconds = (time.perf_counter() - t0) / 6
             del sf, step
             # (no empty_cache() between trials: rank 0's frame buffers have the same size in every trial, so the
             # caching allocator hands them straight back; returning gigabytes to the driver instead makes it scrub
             # them in the background, and whatever is timed in the next second reads up to twice too high --
             # tools/fresh_memory_probe.py, profiles/r03/README.md)
+            trial[cand] = max_over_ranks(seconds)
             if args.gather == "dense" and len(trial) >= 3:
                 times = list(trial.values())
                 if times[-1] > times[-2] > times[-3]:  # past the minimum: larger shares only get slower
                     break
+            if max_over_ranks(time.perf_counter() - t_begin) > budget_s:
+                note = f"stopped after {len(trial)} of {len(candidates)} candidates: the calibration's {budget_s:.0f} s were spent"
+                break
         torch.cuda.empty_cache()  # once, before the real pipeline is built (the settle phase follows)
+        if not trial:
+            return (1, 1), {"fallback": "1:1", "reason": note or "no candidate completed"}
         floor = min(trial.values())
         best = min((c for c in trial if trial[c] <= 1.02 * floor), key=lambda c: (max(c) / min(c), trial[c]))
-        return best, {"ms_per_step_by_share": {f"{c[0]}:{c[1]}": round(v * 1e3, 4) for c, v in trial.items()}}
+        out = {"ms_per_step_by_share": {f"{c[0]}:{c[1]}": round(v * 1e3, 4) for c, v in trial.items()}}
+        if note:
+            out["note"] = note
+        return best, out
 
     # ---- the headline sequence
-    sharded = world > 1 and args.shard in ("stripes", "bands")
+    sharded = dist_on and args.shard in ("stripes", "bands")
     count_group = fill_stream = None
     consumer_stream = torch.cuda.Stream(device=device) if sharded else None
     if sharded and args.gather == "sparse":
         # message sizes travel between the hosts over a CPU group, beside the RCCL transfers
         if args.backend == "nccl":
+            stage("gloo side group")
             try:
                 count_group = dist.new_group(backend="gloo")
             except Exception as e:  # every rank sees the same environment: all fall back together
@@ -761,11 +983,14 @@ def main():
         # rank 0 keeps two buffers of the step's finished frames: at most 24 GB of them (8K frames: 90)
         frames_per_step = max(1, min(frames_per_step, int(24e9 // (2 * 4 * W * H))))
         if args.shard == "stripes":
-            if args.root_weight == "auto":
+            if args.root_weight == "auto" and world > 1:
                 root_weight, calibration = calibrate_root_weight(frames_per_step)
-            else:
+            elif args.root_weight != "auto":
                 parts = [max(1, int(x)) for x in str(args.root_weight).split(":")]
                 root_weight = (parts[0], parts[1] if len(parts) > 1 else 1)
+                if args.calibration_note:  # a relaunch by self_launch() after the calibration of the first attempt stalled
+                    calibration = {"fallback": f"{root_weight[0]}:{root_weight[1]}", "reason": args.calibration_note}
+        stage("build pipeline")
         pipe, step = row_shards(frames_per_step, args.camera, contiguous=(args.shard == "bands"),
                                 root_weight=root_weight)
         rows0 = pipe.rows[rank]
@@ -784,16 +1009,18 @@ def main():
     # short run asks for (5 ms of GPU time; 20 timed steps then read 3 % low).  Steps settle_first ..: the
     # step numbering of warm-up and timed steps continues after them.
     settle_steps = settle_count(frames_per_step) if not args.whole_orbit else 2
+    stage(f"settle ({settle_steps} steps)")
     for k in range(settle_steps):
         step(k)
     pipe.wait_all()
     torch.cuda.synchronize()
     base_step = [settle_steps]
-    m = run(pipe, lambda k: step(k + base_step[0]), args.steps, args.warmup)
+    m = run(pipe, lambda k: step(k + base_step[0]), args.steps, args.warmup, announce=True)
     elapsed = m["elapsed"]
 
     check = None
-    if args.check or (world > 1 and not args.no_check):
+    if args.check or (dist_on and not args.no_check):
+        stage("check (gathered frames against single-GPU renders)")
         last = settle_steps + args.warmup + args.steps - 1
         if rank == 0:
             ref = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
@@ -826,7 +1053,8 @@ def main():
     if not args.no_secondary:
         sec_steps = max(20, min(args.steps, 200))
         sec_warm = max(6, min(args.warmup, 20))
-        if world == 1:
+        if not dist_on:
+            stage("secondary lone_frame / orbit_x8 / fixed_camera")
             if B != 1:
                 p2, s2 = whole_frames(1, "orbit")
                 secondary["lone_frame"] = summarise(
@@ -846,6 +1074,7 @@ def main():
                 # the north star also asks for 4096 x 4096 (BASELINE cfg 4: 512 steps / 16 iterations) and every report
                 # carries the reference's own constants (100 / 10, GUI-default c): measured here, in the driver's run
                 torch.cuda.empty_cache()
+                stage("secondary cfg4_julia_4096 / ref_constants / cfg3")
                 short = max(8, min(args.steps, 24))
                 secondary["cfg4_julia_4096"] = {
                     "batched": measure_workload("cfg4_julia_4096", local_rank, 16, short, 4, args.encode),
@@ -859,6 +1088,7 @@ def main():
                                                                       args.encode)
                 if args.cfg5_secondary == "auto":
                     torch.cuda.empty_cache()
+                    stage("cfg5 whole orbit (two child processes)", deadline_s=2 * 170.0)
                     for name, wl, what in (("cfg5_whole_orbit", "cfg5_sierpinski_8k_orbit_shadows",
                                             "with the soft-shadow secondary rays BASELINE config 5 names (an extension: the reference has none)"),
                                            ("cfg5_whole_orbit_reference_shading", "cfg5_sierpinski_8k_orbit",
@@ -872,23 +1102,59 @@ def main():
                                 "note": "all 120 frames of the 7680x4320 Sierpinski orbit (256 march steps, 16 folds), " + what +
                                         "; every frame resident in HBM; one step = the whole orbit; run in a child process"})
         elif args.shard != "frames":
+            stage("secondary frame_parallel")
             p4, s4 = whole_frames(B, args.camera, deliver=False)
             mm = run(p4, s4, sec_steps, sec_warm)
-            t = torch.tensor([mm["elapsed"]], dtype=torch.float64,
-                             device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            mm["elapsed"] = float(t.item())
+            mm["elapsed"] = max_over_ranks(mm["elapsed"])
             sec = summarise(mm, B, sec_steps, f"frame-parallel: every rank renders whole frames ({B} per launch) and "
                             "keeps them in its own HBM; no exchange step, so NOT the north star's gathered frame")
             sec["mpix_s"] = round(sec["mpix_s"] * world, 2)  # whole job: N ranks x B frames per step
             secondary["frame_parallel"] = sec
+            del p4, s4
+            if sharded and key == HEADLINE:
+                # the north star's other size at every N: 4096 x 4096 (BASELINE cfg 4: 512 steps / 16 iterations) through the
+                # SAME sharded pipeline -- row shards, sparse records gathered on rank 0, rank 0 : peer as calibrated above
+                stage("secondary cfg4_julia_4096 through the sharded pipeline")
+                torch.cuda.empty_cache()
+                sc4 = other_scene("cfg4_julia_4096")
+                f4 = 16 * world if args.scaling == "weak" else 16
+                f4 = max(1, min(f4, K.MAX_BATCH, int(24e9 // (2 * 4 * sc4.W * sc4.H))))
+                p6, s6 = row_shards(f4, "orbit", contiguous=(args.shard == "bands"), root_weight=root_weight, scene=sc4)
+                steps4 = max(6, min(args.steps, 16))
+                mm = run(p6, s6, steps4, 3, scene=sc4)
+                ms4 = max_over_ranks(mm["elapsed"]) / steps4 * 1e3
+                check4 = None
+                if rank == 0 and not args.no_check:  # first and last frame of the last step against single-GPU renders
+                    last4 = 3 + steps4 - 1
+                    ref4 = torch.empty((sc4.H, sc4.W, 4), dtype=torch.uint8, device=device)
+                    check4 = True
+                    for i in (0, f4 - 1):
+                        sc4.gs.set_raw_uniforms(camera=sc4.cameras(last4 * f4 + i, 1, "orbit")[0])
+                        sc4.gs.render(out=ref4, encode=args.encode)
+                        check4 = check4 and bool(torch.equal(p6.frames(last4)[i], ref4))
+                    del ref4
+                k4 = mm["kernel_ms"] if mm["launches_timed"] else ms4
+                rows4 = p6.rows[rank]
+                secondary["cfg4_julia_4096"] = {
+                    "workload": "cfg4_julia_4096", "width": sc4.W, "height": sc4.H, "frames_per_step": f4, "steps": steps4,
+                    "ms_per_step": round(ms4, 5), "mpix_s": round(f4 * sc4.W * sc4.H / (ms4 * 1e-3) / 1e6, 2),
+                    "kernel": mm["kernel"], "kernel_ms": round(k4, 5),
+                    "hbm_frac": round(4.0 * sc4.W * rows4 * min(f4, K.MAX_BATCH) / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "rows_per_rank": list(p6.rows), "check": check4,
+                    "note": f"4096x4096 quaternion-Julia, 512 march steps, 16 SDF iterations, orbit camera, {world} GPU(s): row "
+                            "shards of every frame gathered on rank 0 like the headline; mpix_s is the whole job's; hbm_frac = "
+                            "rank 0's rows x 4 B / its kernel time / 8 TB/s"}
+                del p6, s6
+                sc4.gs.close()
+                torch.cuda.empty_cache()
+                if check4 is False:
+                    check = False
 
     # ---- reduce over ranks
-    if world > 1:
+    if dist_on:
+        stage("reduce over ranks")
         red_dev = device if args.backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed)
         mine = torch.tensor([m["kernel_ms"] * launches_per_step, m["elapsed"] / args.steps * 1e3],
                             dtype=torch.float64, device=red_dev)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
@@ -912,9 +1178,12 @@ def main():
             for g in gss:
                 g.close()
             dist.destroy_process_group()
+            stage("done")
+            _STAGE["name"] = "done"
             return
         del pipe, step
         torch.cuda.empty_cache()
+        stage("one-process child (kifs_multi_render_batch_async, RCCL inside the library)")
         one_proc = child_line(
             ["--gpus", str(world), "--host", "one-process", "--steps", str(min(args.steps, 40)), "--warmup", str(min(args.warmup, 8)),
              "--workload", key, "--frames-per-launch", str(B), "--gather", args.gather, "--scaling", args.scaling,
@@ -934,8 +1203,8 @@ def main():
         launch_s = (m["kernel_ms"] if m["launches_timed"] else elapsed / args.steps * 1e3) / 1e3
         alg_bytes = 4.0 * W * rows0 * frames_per_launch  # rank 0's rows of the launch's frames
         achieved = alg_bytes / launch_s / 1e9
-        traffic, traffic_source, pmc = pmc_traffic(key, frames_per_launch) if world == 1 else (None, None, None)
-        if world == 1:
+        traffic, traffic_source, pmc = pmc_traffic(key, frames_per_launch) if not dist_on else (None, None, None)
+        if world == 1 and not sharded:
             parallelism = (f"1 GPU, {B} frame(s) of the sequence per launch"
                            + (f", {F} launches in flight" if F > 1 else ""))
         elif sharded:
@@ -984,7 +1253,7 @@ def main():
             "per_rank_kernel_ms": [round(x, 5) for x in per_rank_kernel_ms],
             "per_rank_step_ms": [round(x, 5) for x in per_rank_step_ms],
         }
-        if world > 1:
+        if dist_on:
             out["comm"] = {"backend": ("rccl (torch.distributed backend 'nccl')" if args.backend == "nccl" else "gloo (rehearsal)"),
                            "world_size_seen": dist.get_world_size(),
                            "count_channel": (None if not (sharded and args.gather == "sparse") else
@@ -1022,14 +1291,17 @@ def main():
         if check is not None:
             out["gathered_frame_equals_single_gpu_frame"] = check
         if world == 1 and args.cpu_seconds > 0:
+            stage("cpu baseline", deadline_s=args.cpu_seconds + 170.0)
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
             out["roofline"]["secondary"] = work_count(w, launch_s / frames_per_launch)
         print(json.dumps(out), flush=True)
 
     for g in gss:
         g.close()
-    if world > 1 and dist.is_initialized():
+    if dist_on and dist.is_initialized():
         dist.destroy_process_group()
+    stage("done")
+    _STAGE["name"] = "done"
     if check is False:
         sys.exit("bench.py: gathered frames differ from single-GPU frames")
 

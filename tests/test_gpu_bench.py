@@ -89,6 +89,10 @@ def test_two_ranks_are_started_by_bench_itself_and_gather_exact_frames():
     assert comm["backend"].startswith("gloo") and comm["world_size_seen"] == 2 and comm["gather"] == "sparse"
     assert comm["check"] is True
     # ... and, once the ranks' own collectives are over, the same two "devices" driven by ONE process through the C ABI
+    # the north star's other size, through the same sharded pipeline
+    c4 = d["secondary"]["cfg4_julia_4096"]
+    assert c4["width"] == c4["height"] == 4096 and c4["frames_per_step"] == 32 and sum(c4["rows_per_rank"]) == 4096
+    assert c4["check"] is True and c4["mpix_s"] > 1000.0 and 0 < c4["hbm_frac"] < 1
     one = d["secondary"]["one_process_c_abi"]
     assert "error" not in one, one
     assert one["value"] > 1000.0 and one["frames_per_step"] == 8 and one["comm"]["check"] is True
@@ -131,3 +135,75 @@ def test_whole_orbit_step():
     assert wo["frames"] == 120 and wo["launches_per_step"] == 3 and wo["resident_bytes"] == 120 * 1920 * 1080 * 4
     assert abs(wo["total_ms"] - d["ms_per_step"]) < 1e-3
     assert abs(d["value"] - 120 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+
+
+def _run_raw(*args, env=None, timeout=600):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True,
+                          timeout=timeout, env=e, cwd=str(ROOT))
+
+
+def test_the_rccl_backend_with_a_world_of_one_rank():
+    """The environment half of a multi-GPU run, on the one GPU of this box: --dist-at-one runs
+    bench.py's N > 1 code path with world size 1 over the REAL backend -- init_process_group("nccl", device_id=...),
+    barrier(device_ids=...), all_reduce / all_gather on the device, the gloo side group for the message sizes, the
+    sharded pipeline (no peers), the default frame check, frame_parallel and the 4096 x 4096 figure through the
+    sharded pipeline, destroy_process_group -- so that hardware day only adds the second rank."""
+    p = _run_raw("--dist-at-one", "--steps", "4", "--warmup", "2", "--cpu-seconds", "0", "--frames-per-launch", "4")
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    comm = d["comm"]
+    assert comm["backend"].startswith("rccl") and comm["world_size_seen"] == 1 and comm["check"] is True
+    assert comm["count_channel"] == "gloo side group" and comm["gather"] == "sparse"
+    assert d["n_gpus"] == 1 and d["config"]["rows_per_rank"] == [1080] and "row shards" in d["config"]["parallelism"]
+    assert d["secondary"]["cfg4_julia_4096"]["check"] is True and "frame_parallel" in d["secondary"]
+    for name in ("import", "init process group (nccl)", "gloo side group", "build pipeline", "settle", "warmup", "timed",
+                 "check", "secondary frame_parallel", "secondary cfg4_julia_4096", "reduce over ranks", "done"):
+        assert f"bench.py[rank 0] stage: {name}" in p.stderr, name
+    # and torch.distributed's own pieces the pipeline relies on at N > 1, with this rank as its own peer
+    code = """
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+dist.barrier(device_ids=[0])
+t = torch.arange(4, dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+g = dist.new_group(backend="gloo"); c = torch.tensor([7]); out = [torch.zeros(1, dtype=torch.int64)]
+dist.gather(c, out, dst=0, group=g)
+src = torch.arange(1040 * 3, dtype=torch.int32, device=dev).to(torch.uint8); dst = torch.zeros_like(src)
+for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, dst, 0), dist.P2POp(dist.isend, src, 0)]): w.wait()
+torch.cuda.synchronize()
+assert torch.equal(src, dst) and int(out[0]) == 7 and t.tolist() == [0.0, 1.0, 2.0, 3.0]
+dist.destroy_process_group(); print("ok")
+"""
+    q = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0 and q.stdout.strip().endswith("ok"), q.stderr[-2000:]
+
+
+def test_a_rank_asleep_in_the_timed_steps_ends_the_run_and_names_the_stage():
+    """VERDICT r03 item 1 'done': the gloo --share-device rehearsal with one rank made to sleep in a stage ends within
+    the deadline, rc != 0, naming the stage.  (120 + 0.5 x 4) s x 0.1: the timed steps get 12 s.)"""
+    import time
+    t0 = time.time()
+    p = _run_raw("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "4", "--warmup", "2", "--cpu-seconds", "0",
+                 "--frames-per-launch", "4", "--root-weight", "1", "--no-secondary",
+                 env={"KIFS_BENCH_STALL": "timed:1", "KIFS_BENCH_DEADLINE_SCALE": "0.1"})
+    assert p.returncode != 0 and time.time() - t0 < 150, p.stderr[-2000:]
+    assert "STALLED in stage 'timed (4 steps)'" in p.stderr or "stalled in stage 'timed (4 steps)'" in p.stderr
+    assert "last stage of every rank" in p.stderr and "'timed (4 steps)'" in p.stderr.split("last stage of every rank")[-1]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_stalled_calibration_falls_back_to_even_shares_in_a_fresh_launch():
+    """... and a calibration that stalls costs the calibration, not the run: self_launch() starts the ranks once more
+    (fresh children; the parent never touches the GPU) with --root-weight 1:1 and the line says so."""
+    p = _run_raw("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "4", "--warmup", "2", "--cpu-seconds", "0",
+                 "--frames-per-launch", "4", "--no-secondary",
+                 env={"KIFS_BENCH_STALL": "calibration 2:1", "KIFS_BENCH_DEADLINE_SCALE": "0.1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "starting the ranks once more with --root-weight 1:1" in p.stderr
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    cal = d["config"]["root_weight_calibration"]
+    assert cal["fallback"] == "1:1" and "calibration 2/7" in cal["reason"]
+    assert d["config"]["root_weight"] == d["config"]["peer_weight"] == 1 and d["comm"]["check"] is True
