@@ -27,6 +27,7 @@
 // Replaces: vs_main + rasteriser + fs_main + ROP of the reference
 // (src/shaders/dependencies/entry.wgsl:35-59, src/render/graphics.rs:310-325,
 // src/render.rs:72-80).
+#include <atomic>
 #include <cstdlib>
 
 #include "kifs_render_common.hpp"
@@ -761,14 +762,16 @@ static hipError_t launch_variant(const BatchParams& B, hipStream_t stream) {
     if (pad > 48 * 1024) {
         // beyond the default dynamic-LDS limit: opt in once per kernel AND per device (the
         // attribute belongs to the device's copy of the code object)
-        static bool opted_in[64] = {};
+        // (two contexts on two threads may come through here at once -- the header allows one caller thread per
+        // context -- hence atomics; setting the attribute twice is harmless, a torn flag would not be)
+        static std::atomic<bool> opted_in[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-        if (dev < 0 || dev >= 64 || !opted_in[dev]) {
+        if (dev < 0 || dev >= 64 || !opted_in[dev].load(std::memory_order_acquire)) {
             hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<GROUP, PRIM>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (attr != hipSuccess) return attr;
-            if (dev >= 0 && dev < 64) opted_in[dev] = true;
+            if (dev >= 0 && dev < 64) opted_in[dev].store(true, std::memory_order_release);
         }
     }
     if (P.round_steps > 0 && P.group_tiles == 0) {  // the throughput path, one wave per tile
