@@ -260,7 +260,10 @@ def self_launch(args, attempt=0, extra=()):
             if any(p.returncode not in (None, 0) for p in procs):
                 # a rank that dies leaves the others waiting in a collective: stop them (exactly the
                 # children started above) instead of waiting for a communicator time-out
-                failed = f"a rank failed (exit codes {[p.returncode for p in procs]})"
+                with lock:
+                    where = {r: last[r][0] for r, p in enumerate(procs) if p.returncode not in (None, 0)}
+                failed = (f"rank(s) {sorted(where)} exited with code(s) {[procs[r].returncode for r in sorted(where)]} in stage(s) "
+                          + ", ".join(f"'{where[r]}'" for r in sorted(where)))
                 stop_children()
                 break
             now = time.time()
@@ -374,16 +377,49 @@ def work_count(w, kernel_s):
 
 
 def pmc_traffic(workload_key, frames_per_launch=1):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (counters cannot be read from
-    inside the process), keyed by workload and workload@B; (bytes or None, source)."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (counters cannot be read from inside the process),
+    keyed by workload and workload@B: (bytes or None, source, record or None, note or None).  Every entry carries the
+    kernel hash of the library it was measured on (kifs_raymarching_amd/build.py: kernel_hash()); an entry that belongs
+    to other kernels than the ones loaded is NOT reported -- new kernels must not carry old counters."""
+    import kifs_raymarching_amd as K
     p = ROOT / "profiles" / "pmc_traffic.json"
     if frames_per_launch > 1:
         workload_key = f"{workload_key}@{frames_per_launch}"
     try:
         rec = json.loads(p.read_text()).get(workload_key)
-        return (rec["hbm_bytes_per_launch"] if rec else None), "profiles/pmc_traffic.json", rec
-    except (OSError, ValueError, KeyError):
-        return None, None, None
+    except (OSError, ValueError):
+        return None, None, None, None
+    if not rec:
+        return None, "profiles/pmc_traffic.json", None, f"no counter pass recorded for {workload_key}"
+    loaded = K._lib.kernel_hash_of_loaded_library()
+    if not loaded or rec.get("kernel_hash") != loaded:
+        return (None, "profiles/pmc_traffic.json", None,
+                f"the recorded counter pass ({rec.get('round', '?')}) belongs to other kernels than the loaded library's "
+                f"(kernel hash {str(rec.get('kernel_hash'))[:12]} != {loaded[:12] or 'unstamped'}): re-run tools/profile_round.sh")
+    return rec.get("hbm_bytes_per_launch"), "profiles/pmc_traffic.json", rec, None
+
+
+def lone_frame_floor(workload_key, camera_mode):
+    """The committed floor under a lone frame (tools/lone_frame_floor.py: the critical ray's instructions, counted from
+    the source of the long-ray loop and the instrumented oracle, x a lone wave's issue interval), if it belongs to the
+    loaded kernels: (floor_ms or None, note)."""
+    import kifs_raymarching_amd as K
+    try:
+        rec = json.loads((ROOT / "profiles" / "lone_frame_floor.json").read_text()).get(workload_key)
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None, "no floor recorded for this workload (tools/lone_frame_floor.py)"
+    loaded = K._lib.kernel_hash_of_loaded_library()
+    if not loaded or rec.get("kernel_hash") != loaded:
+        return None, "the recorded floor was counted from other kernel sources than the loaded library's: re-run tools/lone_frame_floor.py"
+    return rec["floor_ms_orbit_mean" if camera_mode == "orbit" else "floor_ms_fixed_view"], (
+        f"critical ray's instructions ({rec['instructions_per_step']['inside_fixed']} per march step inside the bounding "
+        f"sphere + {rec['instructions_per_step']['per_orbit_trip']} per orbit trip, counted from kifs_julia_march_asm.hpp; the "
+        f"ray from the instrumented oracle, {'mean over sampled orbit poses' if camera_mode == 'orbit' else 'the fixed view'}) x "
+        f"{rec['issue_cycles']} cycles per instruction of a lone wave (tools/microbench/issue_cost) at {rec['clock_hz'] / 1e9:.1f} GHz; "
+        "taken branches, wait states, set-up, shading and the store are not in it")
+
 
 def measure_workload(name, local_rank, B, steps, warmup, encode, camera_mode="orbit", settle_ms=30.0):
     """One more workload in the same process, after the timed region: its own context, stream and buffers; `steps`
@@ -1059,7 +1095,13 @@ def main():
                 p2, s2 = whole_frames(1, "orbit")
                 secondary["lone_frame"] = summarise(
                     run(p2, s2, sec_steps, sec_warm), 1, sec_steps,
-                    "one frame per launch, a new orbit pose and a 64-byte camera upload per frame: the latency path")
+                    "one frame per launch, a new orbit pose and a 64-byte camera upload per frame: the latency path "
+                    "(the reference's own call pattern, graphics.rs:324)")
+                floor_ms, floor_note = lone_frame_floor(key, "orbit")
+                lf = secondary["lone_frame"]
+                lf["floor_ms"] = floor_ms
+                lf["frac_of_floor"] = round(floor_ms / lf["kernel_ms"], 4) if floor_ms and lf["kernel_ms"] > 0 else None
+                lf["floor_note"] = floor_note
             if B != 8:
                 p5, s5 = whole_frames(8, "orbit")
                 secondary["orbit_x8"] = summarise(
@@ -1203,7 +1245,7 @@ def main():
         launch_s = (m["kernel_ms"] if m["launches_timed"] else elapsed / args.steps * 1e3) / 1e3
         alg_bytes = 4.0 * W * rows0 * frames_per_launch  # rank 0's rows of the launch's frames
         achieved = alg_bytes / launch_s / 1e9
-        traffic, traffic_source, pmc = pmc_traffic(key, frames_per_launch) if not dist_on else (None, None, None)
+        traffic, traffic_source, pmc, traffic_note = pmc_traffic(key, frames_per_launch) if not dist_on else (None, None, None, None)
         if world == 1 and not sharded:
             parallelism = (f"1 GPU, {B} frame(s) of the sequence per launch"
                            + (f", {F} launches in flight" if F > 1 else ""))
@@ -1273,6 +1315,8 @@ def main():
                 out["config"]["tiles_sent_fraction"] = tiles_sent_fraction
             if calibration:
                 out["config"]["root_weight_calibration"] = calibration
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
         if pmc and pmc.get("valu_instructions_per_launch") and pmc.get("kernel_cycles"):
             # what actually bounds the kernel: the vector pipes.  From the same committed PMC passes: VALU
             # wave-instructions per launch x 2.25 pipe cycles each (tools/microbench/valu_rate: a full chip

@@ -205,7 +205,7 @@ def _load():
     kb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kb)
     if kb.STAMP.exists() and not kb.is_current():
-        src, _ = kb.recorded()
+        src = kb.recorded()[0]
         why = ("was built from other sources than the ones in csrc/" if src != kb.source_hash()
                else "is not the file the build produced (replaced after the build?)")
         raise ImportError(f"{LIB_PATH} {why} (hash mismatch): rebuild it "
@@ -213,9 +213,10 @@ def _load():
     return _bind(C.CDLL(str(LIB_PATH)))
 
 
-def source_hash_of_loaded_library() -> str:
-    """The source hash recorded when the loaded library was built ("" for a variant or an unstamped library):
-    what profiles/pmc_traffic.json entries are tied to (bench.py)."""
+def kernel_hash_of_loaded_library() -> str:
+    """The kernel hash (build.kernel_hash()) recorded when the loaded library was built; "" for a variant or an
+    unstamped library.  profiles/pmc_traffic.json and profiles/lone_frame_floor.json entries carry the hash of the
+    kernels they were measured on or counted from; bench.py drops the ones that are not this library's."""
     import importlib.util
     import os
     if os.environ.get("KIFS_LIB_VARIANT") and os.environ.get("KIFS_TUNING") == "1":
@@ -223,7 +224,7 @@ def source_hash_of_loaded_library() -> str:
     spec = importlib.util.spec_from_file_location("_kifs_build_check", PKG_DIR / "build.py")
     kb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kb)
-    return kb.recorded()[0]
+    return kb.recorded()[2]
 
 
 def _bind(lib):

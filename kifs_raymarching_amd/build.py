@@ -21,31 +21,45 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def kernel_hash() -> str:
+    """Hash of what decides the DEVICE code and the launch shapes: the kernel files, every header, the scheduling rules
+    (kifs_schedule.cpp) and the Makefile's flags -- what a profile's counters and an instruction count belong to.
+    Host-only edits (kifs_api / kifs_multi / kifs_shards / kifs_host) leave it alone."""
+    h = hashlib.sha256()
+    files = sorted(p for p in CSRC.iterdir()
+                   if p.suffix in (".hip", ".hpp", ".h") or p.name in ("Makefile", "kifs_schedule.cpp"))
+    for p in files:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
 def library_hash() -> str:
     return hashlib.sha256(LIB.read_bytes()).hexdigest() if LIB.exists() else ""
 
 
 def write_stamp() -> None:
-    """Two lines: the hash of the sources the library was built from, and the hash of the library file itself --
-    so that a library copied over the built one (a sweep's variant) is noticed as well as an edited source."""
-    STAMP.write_text(source_hash() + "\n" + library_hash() + "\n")
+    """Three lines: the hash of the sources the library was built from, the hash of the library file itself -- so that
+    a library copied over the built one (a sweep's variant) is noticed as well as an edited source -- and the
+    kernel hash (kernel_hash(): what profiles/pmc_traffic.json and profiles/lone_frame_floor.json entries are tied to)."""
+    STAMP.write_text(source_hash() + "\n" + library_hash() + "\n" + kernel_hash() + "\n")
 
 
 def recorded() -> tuple:
-    """(source hash, library hash) of the stamp; ("", "") without one."""
-    if not STAMP.exists():
-        return "", ""
-    lines = STAMP.read_text().split()
-    return (lines[0] if lines else ""), (lines[1] if len(lines) > 1 else "")
+    """(source hash, library hash, kernel hash) of the stamp; empty strings without one."""
+    lines = STAMP.read_text().split() if STAMP.exists() else []
+    return tuple(lines[i] if len(lines) > i else "" for i in range(3))
 
 
 def is_current() -> bool:
-    src, lib = recorded()
+    src, lib, _ = recorded()
     return LIB.exists() and src == source_hash() and lib == library_hash()
 
 
 def build(force: bool = False) -> None:
     if not force and is_current():
+        if recorded()[2] != kernel_hash():  # (a stamp from before the kernel hash existed)
+            write_stamp()
         return
     subprocess.run(["make", "-C", str(CSRC), "-B"], check=True)
     write_stamp()

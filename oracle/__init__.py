@@ -186,6 +186,25 @@ def render(screen, camera, options, it=None, encode=1, y0=0, y1=None, nthreads=0
     return out
 
 
+def render_ray_costs(screen, camera, options, it=None, y0=0, y1=None):
+    """Per pixel of rows [y0, y1): (scene_SDF calls of the march, calls past the bounding-sphere early-out, inner
+    iterations) as three (rows, W) arrays -- kor_render_ray_costs; what shading adds after the march is not counted."""
+    w, h = int(screen.width), int(screen.height)
+    y1 = h if y1 is None else y1
+    it = it or iters()
+    calls = np.zeros((y1 - y0, w), dtype=np.uint16)
+    inside = np.zeros((y1 - y0, w), dtype=np.uint16)
+    inner = np.zeros((y1 - y0, w), dtype=np.uint32)
+    fn = lib().kor_render_ray_costs
+    fn.restype = C.c_int
+    rc = fn(C.byref(screen), C.byref(camera), C.byref(options), C.byref(it), C.c_int(y0), C.c_int(y1),
+            calls.ctypes.data_as(C.POINTER(C.c_uint16)), inside.ctypes.data_as(C.POINTER(C.c_uint16)),
+            inner.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc != 0:
+        raise ValueError("kor_render_ray_costs: bad arguments")
+    return calls, inside, inner
+
+
 def render_stats(screen, camera, options, it=None, encode=1, y0=0, y1=None):
     w, h = int(screen.width), int(screen.height)
     y1 = h if y1 is None else y1

@@ -66,7 +66,8 @@ typedef struct {
     int32_t sdf_iters, normal_iters, fold_iters;
     KorExt ext; /* extension block, all zero = reference behaviour */
     /* counters (instrumented run only) */
-    uint64_t n_sdf, n_inner;
+    uint64_t n_sdf, n_inner, n_inside; /* n_inside: SDF calls that got past the bounding-sphere early-out */
+    uint64_t shade_inner, shade_inside; /* the share of get_normal (+ the extension's secondary ray) in the two above */
 } Scene;
 
 static void scene_init(Scene* s, const KorScreen* sc, const KorCamera* cam, const KorOptions* o,
@@ -165,6 +166,7 @@ static float julia_sdf(Scene* s, v3 p) {
     s->n_sdf++;
     float norm = len3(p);                       /* julia.wgsl:7 */
     if (norm > 2.0f + s->epsilon) return norm - 2.0f; /* :8-10 */
+    s->n_inside++;
 
     v4 q = {p.x, p.y, p.z, 0.1f};               /* :12, w = 0.1 (:1) */
     float qs = quat_norm2(q);                   /* :13 */
@@ -212,6 +214,7 @@ static float genjulia_sdf(Scene* s, v3 p) {
     s->n_sdf++;
     float norm = len3(p);
     if (norm > 2.0f + s->epsilon) return norm - 2.0f; /* gen_julia.wgsl:7-10 */
+    s->n_inside++;
     v4 q = {p.x, p.y, p.z, 0.1f};
     float d = quat_ijk2(q);
     float qs = fma_(q.x, q.x, d);               /* = quat_norm2(q) */
@@ -346,6 +349,7 @@ static float bunny_sdf(v3 p) { /* kifs.wgsl:84-137 */
 
 static float kifs_sdf(Scene* s, v3 p) { /* kifs.wgsl:139-155 */
     s->n_sdf++;
+    s->n_inside++;
     switch (s->primitive) {
     case 0: /* sphere r=1, :20-22 */
         return len3(p) - 1.0f;
@@ -454,10 +458,13 @@ static int raymarch(Scene* s, v3 dir, float rgba[4], int* hit_out) {
     for (i = 0; i < s->max_iterations && t < s->max_distance; i++) { /* :12 */
         float d = scene_sdf(s, p);                                    /* :13 */
         if (d < s->epsilon) {                                         /* :15 */
+            const uint64_t inner0 = s->n_inner, inside0 = s->n_inside; /* (instrumentation only) */
             v3 n = scene_normal(s, p);                                /* :16 */
             float ndl = (n.x + n.y) + n.z; /* dot(n, (1,1,1)), :17 */
             float lit = clamp_(ndl, 0.0f, 1.0f);
             if (s->ext.soft_shadow && lit > 0.0f) lit = lit * soft_shadow(s, p, n); /* extension */
+            s->shade_inner += s->n_inner - inner0;
+            s->shade_inside += s->n_inside - inside0;
             float diffuse = fma_(0.9f, lit, 0.1f);
             out_r = diffuse * s->fractal_color.x;                     /* :19 */
             out_g = diffuse * s->fractal_color.y;
@@ -631,6 +638,35 @@ int kor_render_stats(const KorScreen* screen, const KorCamera* camera, const Kor
     st.sdf_calls = s.n_sdf;
     st.inner_iters = s.n_inner;
     if (stats) *stats = st;
+    return 0;
+}
+
+/* Per-ray work of the MARCH (instrumented; test and measurement tooling only): for every pixel of rows [y0, y1) the
+ * number of scene_SDF calls its march made (`calls`: the loop counter, +1 when it ended on a hit), how many of them got
+ * past the bounding-sphere early-out (`inside`: julia.wgsl:7-10; every call for the KIFS pipeline) and the inner
+ * iterations they ran (`inner`: Julia iterations / Sierpinski folds).  What get_normal (and the extension's secondary
+ * ray) adds after the march is not counted.  Arrays of (y1 - y0) * width entries; any of them may be NULL. */
+int kor_render_ray_costs(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
+                         const KorIters* iters, int y0, int y1, uint16_t* calls, uint16_t* inside, uint32_t* inner) {
+    uint8_t px[4];
+    if (check_args(screen, camera, options, y0, y1, px, (size_t)-1)) return -1; /* (no frame is written) */
+    pthread_once(&g_srgb_once, srgb_init);
+    Scene s;
+    scene_init(&s, screen, camera, options, iters);
+    int w = (int)screen->width;
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < w; x++) {
+            float rgba[4];
+            int hit;
+            const uint64_t in0 = s.n_inside - s.shade_inside, it0 = s.n_inner - s.shade_inner;
+            int i = raymarch(&s, ray_direction(&s, x, y), rgba, &hit);
+            const uint32_t steps = (uint32_t)i + (hit ? 1u : 0u);
+            const uint64_t din = (s.n_inside - s.shade_inside) - in0, dit = (s.n_inner - s.shade_inner) - it0;
+            const size_t k = (size_t)(y - y0) * (size_t)w + (size_t)x;
+            if (calls) calls[k] = (uint16_t)(steps > 65535u ? 65535u : steps);
+            if (inside) inside[k] = (uint16_t)(din > 65535u ? 65535u : din);
+            if (inner) inner[k] = (uint32_t)dit;
+        }
     return 0;
 }
 

@@ -109,6 +109,10 @@ int kor_render_stats(const KorScreen* screen, const KorCamera* camera, const Kor
                      const KorIters* iters, int encode, int y0, int y1, uint8_t* out,
                      size_t pitch, KorStats* stats, uint16_t* steps_out);
 
+/* Per-ray work of the march (instrumented): scene_SDF calls, those past the bounding-sphere early-out, inner iterations. */
+int kor_render_ray_costs(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
+                         const KorIters* iters, int y0, int y1, uint16_t* calls, uint16_t* inside, uint32_t* inner);
+
 /* Linear (pre-encode) colour of one pixel; rgba[4] f32.  Returns loop counter i. */
 int kor_shade_pixel(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
                     const KorIters* iters, int x, int y, float rgba[4]);

@@ -26,6 +26,7 @@ for w in cfg5_sierpinski_8k_orbit cfg5_sierpinski_8k_orbit_shadows; do
   done
   echo "bench $w done"
 done
+cp $R/kifs_raymarching_amd/libkifs_hip.so.srchash $O/srchash.txt  # which library the counters belong to
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --cpu-seconds 0 --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o cfg2 -- python3 $B --steps 200 --warmup 20 > $O/trace.log 2>&1

@@ -12,6 +12,7 @@ O=$R/gpurun_out/prof_stalls
 mkdir -p $O
 LIST="$@"
 [ -z "$LIST" ] && LIST="cfg2_julia_1080p@48 cfg3_sierpinski_1080p@48 ref_julia_1080p@48 n1_genjulia_1080p@48 n2_bunny_1080p@8 n2_bunny_1080p@48 cfg2_julia_1080p@1"
+cp $R/kifs_raymarching_amd/libkifs_hip.so.srchash $O/srchash.txt  # which library the counters belong to
 cd /tmp && export TMPDIR=/tmp
 PA="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"
 PB="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS"

@@ -21,6 +21,14 @@ SRC = ROOT / "gpurun_out" / "prof"
 SIMDS = 1024  # 256 CUs x 4
 
 
+
+def profiled_kernel_hash(src_dir):
+    """The kernel hash (kifs_raymarching_amd/build.py: kernel_hash()) of the library the passes ran: third line of the
+    stamp the profiling script copied beside its output; "" when the run predates it."""
+    p = Path(src_dir) / "srchash.txt"
+    lines = p.read_text().split() if p.exists() else []
+    return lines[2] if len(lines) > 2 else ""
+
 def find_csv(d, suffix):
     hits = sorted(Path(d).rglob(f"*{suffix}"))
     return hits[0] if hits else None
@@ -78,7 +86,8 @@ def main():
         if "WRITE_SIZE" in rec and "FETCH_SIZE" in rec:
             rec["hbm_bytes_per_launch"] = int(rec["WRITE_SIZE"] * 1024 + 2 * rec["FETCH_SIZE"] * 1024)
             key = "cfg2_julia_1080p" + (f"@{B}" if B > 1 else "")
-            traffic[key] = {"write_size_kib": round(rec["WRITE_SIZE"], 2), "fetch_size_kib": round(rec["FETCH_SIZE"], 2),
+            traffic[key] = {"kernel_hash": profiled_kernel_hash(SRC),
+                            "write_size_kib": round(rec["WRITE_SIZE"], 2), "fetch_size_kib": round(rec["FETCH_SIZE"], 2),
                             "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "kernel": rec["kernel"],
                             "camera": "orbit", "round": rnd}
             if rec.get("SQ_INSTS_VALU") and rec.get("GRBM_GUI_ACTIVE"):

@@ -12,6 +12,7 @@ mkdir -p $O
 LIST="$@"
 [ -z "$LIST" ] && LIST="cfg2_julia_1080p@48 cfg3_sierpinski_1080p@48 cfg4_julia_4096@48 ref_julia_1080p@48 \
 n1_genjulia_1080p@48 n2_bunny_1080p@48 cfg5_sierpinski_8k_orbit@8 cfg5_sierpinski_8k_orbit_shadows@8 cfg1_julia_256@48"
+cp $R/kifs_raymarching_amd/libkifs_hip.so.srchash $O/srchash.txt  # which library the counters belong to
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
 for item in $LIST; do

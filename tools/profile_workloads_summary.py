@@ -31,6 +31,14 @@ SRC = ROOT / "gpurun_out" / "prof_wl"
 SIMDS = 1024
 
 
+
+def profiled_kernel_hash(src_dir):
+    """The kernel hash (kifs_raymarching_amd/build.py: kernel_hash()) of the library the passes ran: third line of the
+    stamp the profiling script copied beside its output; "" when the run predates it."""
+    p = Path(src_dir) / "srchash.txt"
+    lines = p.read_text().split() if p.exists() else []
+    return lines[2] if len(lines) > 2 else ""
+
 def find_csv(d, suffix):
     hits = sorted(Path(d).rglob(f"*{suffix}"))
     return hits[0] if hits else None
@@ -116,7 +124,8 @@ def main():
         summary[d.name] = rec
         if "hbm_bytes_per_launch" in rec:
             key = name + (f"@{B}" if B > 1 else "")
-            traffic[key] = {"write_size_kib": round(counters["WRITE_SIZE"], 2), "fetch_size_kib": round(counters["FETCH_SIZE"], 2),
+            traffic[key] = {"kernel_hash": profiled_kernel_hash(SRC),
+                            "write_size_kib": round(counters["WRITE_SIZE"], 2), "fetch_size_kib": round(counters["FETCH_SIZE"], 2),
                             "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "kernel": kname, "camera": "orbit", "round": rnd}
             if counters.get("SQ_INSTS_VALU") and rec.get("kernel_cycles"):
                 traffic[key]["valu_instructions_per_launch"] = int(counters["SQ_INSTS_VALU"])
