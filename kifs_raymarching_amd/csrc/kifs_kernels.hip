@@ -138,6 +138,12 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     // three counters for two buffers: round r reads count[r % 3], appends under count[(r + 1) % 3] and
     // clears count[(r + 2) % 3], which nobody else touches in that round -- one barrier per round
     __shared__ uint32_t q_count[3], h_count;
+    // The chunks of a round are DRAWN, not dealt: a wave takes the next chunk of the queue from a ticket counter when it
+    // has finished its last one.  A chunk of rays deep inside the bounding sphere costs several times a chunk of rays on
+    // their way in (gen-Julia: 190 instructions per orbit trip against 45 for a step outside), and dealt in turn
+    // (wave w: chunks w, w + 4, ..) the waves with the cheap ones waited at the round's barrier -- SQ_WAIT_ANY was 54 %
+    // of the gen-Julia kernel's wave-cycles, 48 % of the bunny's (profiles/r04/stalls.json).  Same rotation as q_count.
+    __shared__ uint32_t q_ticket[3];
 
     const uint32_t batch = uint32_t(B.count);
     const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
@@ -155,6 +161,9 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
         q_count[0] = 0;
         q_count[1] = 0;
         q_count[2] = 0;
+        q_ticket[0] = 0;
+        q_ticket[1] = 0;
+        q_ticket[2] = 0;
         h_count = 0;
     }
     if (tid < T) {
@@ -203,11 +212,18 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
         const uint32_t n = q_count[cnt];  // uniform
         if (n == 0u) break;
         const uint32_t cnt_next = (cnt + 1u) % 3u;
-        if (tid == 0) q_count[(cnt + 2u) % 3u] = 0;  // the counter of the round after next
+        if (tid == 0) {  // the counters of the round after next
+            q_count[(cnt + 2u) % 3u] = 0;
+            q_ticket[(cnt + 2u) % 3u] = 0;
+        }
         // (one chunk left: nothing more to merge, it is marched to the end -- see render_wave_kernel; not the
         // generalised Julia set, whose compiled march loses 5-10 % that way: 48 frames per launch 20.6 -> 19.6 Gpixel/s)
         const int limit = (GROUP != GROUP_GENJULIA && n <= RAYS) ? P.max_iterations : min(trips + P.round_steps, P.max_iterations);
-        for (uint32_t chunk = uint32_t(wave); chunk * RAYS < n; chunk += uint32_t(BLOCK / 64)) {
+        for (;;) {
+            uint32_t chunk = 0;
+            if (lane == 0) chunk = atomicAdd(&q_ticket[cnt], 1u);
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+            if (chunk * RAYS >= n) break;
             const uint32_t idx = chunk * RAYS + uint32_t(lane) / LPR;  // the LPR lanes of a ray hold the same state
             const bool have = idx < n;
             const bool leader = (uint32_t(lane) % LPR) == 0u;      // the lane that files the ray afterwards

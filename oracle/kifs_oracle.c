@@ -670,6 +670,30 @@ int kor_render_ray_costs(const KorScreen* screen, const KorCamera* camera, const
     return 0;
 }
 
+/* The march of ONE pixel, step by step (tooling for lane-occupancy studies): trips[i] = inner iterations of the i-th
+ * scene_SDF call of the march (0: the call took the bounding-sphere early-out), for the first `max_steps` calls.
+ * Returns the number of calls the march made (the loop counter, +1 on a hit). */
+int kor_march_trace(const KorScreen* screen, const KorCamera* camera, const KorOptions* options, const KorIters* iters,
+                    int x, int y, uint8_t* trips, int max_steps) {
+    Scene s;
+    scene_init(&s, screen, camera, options, iters);
+    v3 dir = ray_direction(&s, x, y);
+    float t = 0.0f;
+    v3 p = s.origin;
+    int i, n = 0;
+    for (i = 0; i < s.max_iterations && t < s.max_distance; i++) { /* entry.wgsl:12-25, shading left out */
+        const uint64_t before = s.n_inner;
+        float d = scene_sdf(&s, p);
+        const uint64_t k = s.n_inner - before;
+        if (n < max_steps) trips[n] = (uint8_t)(k > 255 ? 255 : k);
+        n++;
+        if (d < s.epsilon) break;
+        t = t + d;
+        p = (v3){fma_(t, dir.x, s.origin.x), fma_(t, dir.y, s.origin.y), fma_(t, dir.z, s.origin.z)};
+    }
+    return n;
+}
+
 int kor_shade_pixel(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
                     const KorIters* iters, int x, int y, float rgba[4]) {
     Scene s;

@@ -113,6 +113,10 @@ int kor_render_stats(const KorScreen* screen, const KorCamera* camera, const Kor
 int kor_render_ray_costs(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
                          const KorIters* iters, int y0, int y1, uint16_t* calls, uint16_t* inside, uint32_t* inner);
 
+/* The march of one pixel step by step: inner iterations of every scene_SDF call (0 = bounding-sphere early-out). */
+int kor_march_trace(const KorScreen* screen, const KorCamera* camera, const KorOptions* options, const KorIters* iters,
+                    int x, int y, uint8_t* trips, int max_steps);
+
 /* Linear (pre-encode) colour of one pixel; rgba[4] f32.  Returns loop counter i. */
 int kor_shade_pixel(const KorScreen* screen, const KorCamera* camera, const KorOptions* options,
                     const KorIters* iters, int x, int y, float rgba[4]);
