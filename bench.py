@@ -253,6 +253,12 @@ def self_launch(args, attempt=0, extra=()):
                     p.kill()
                     p.wait()
 
+        def exited_badly():
+            with lock:
+                where = {r: last[r][0] for r, p in enumerate(procs) if p.returncode not in (None, 0)}
+            return (f"rank(s) {sorted(where)} exited with code(s) {[procs[r].returncode for r in sorted(where)]} in stage(s) "
+                    + ", ".join(f"'{where[r]}'" for r in sorted(where)))
+
         failed = None
         # the rank's own watchdog fires first and says where; this is the backstop for a wedged interpreter
         grace = max(1.0, 20.0 * min(1.0, _deadline_scale()))
@@ -260,10 +266,7 @@ def self_launch(args, attempt=0, extra=()):
             if any(p.returncode not in (None, 0) for p in procs):
                 # a rank that dies leaves the others waiting in a collective: stop them (exactly the
                 # children started above) instead of waiting for a communicator time-out
-                with lock:
-                    where = {r: last[r][0] for r, p in enumerate(procs) if p.returncode not in (None, 0)}
-                failed = (f"rank(s) {sorted(where)} exited with code(s) {[procs[r].returncode for r in sorted(where)]} in stage(s) "
-                          + ", ".join(f"'{where[r]}'" for r in sorted(where)))
+                failed = exited_badly()
                 stop_children()
                 break
             now = time.time()
@@ -278,7 +281,7 @@ def self_launch(args, attempt=0, extra=()):
         for t in readers:
             t.join(timeout=5)
         if failed is None and any(p.returncode != 0 for p in procs):
-            failed = f"a rank failed (exit codes {[p.returncode for p in procs]})"
+            failed = exited_badly()
         out0.seek(0)
         sys.stdout.write(out0.read())
         sys.stdout.flush()

@@ -405,7 +405,9 @@ int kifs_eval_points(kifs_ctx* ctx, const float* points_xyz, int n, float* sdf_o
  * 6 pow(x, y) with y = `param`, 7 sRGB-encode (result as float code),
  * 8 UNORM-encode, 9 / 10 the mid-range reciprocal and square root of the generalised-Julia
  * step (correctly rounded for 2^-60 <= x < 2^60; tests check them exhaustively), 11 the branch-free
- * form of sin the bunny network uses (same values as 3). */
+ * form of sin the bunny network uses (same values as 3), 12 / 13 / 14 / 15 / 16 the straight-line cores of the
+ * generalised-Julia step -- exp2, log2, sin, cos, acos for ORDINARY arguments only (|x| < 128; 2^-60 <= x < 2^60;
+ * |x| <= 2^20; |x| <= 1), where they must equal 2 / 1 / 3 / 4 / 5 bit for bit. */
 int kifs_eval_math(kifs_ctx* ctx, int fn, const float* in, float param, float* out, int n);
 
 /* Diagnostics: with enable != 0, subsequent Julia renders write one record per wave into a

@@ -407,7 +407,7 @@ int kifs_eval_points(kifs_ctx* c, const float* pts, int n, float* sdf_out, float
 }
 
 int kifs_eval_math(kifs_ctx* c, int fn, const float* in, float param, float* out, int n) {
-    if (!c || !in || !out || n < 0 || fn < 0 || fn > 11) return KIFS_ERR_BAD_ARG;
+    if (!c || !in || !out || n < 0 || fn < 0 || fn > 16) return KIFS_ERR_BAD_ARG;
     if (n == 0) return KIFS_OK;
     DeviceGuard g(c->device);
     float *d_in = nullptr, *d_out = nullptr;

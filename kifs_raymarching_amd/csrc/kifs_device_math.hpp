@@ -194,8 +194,11 @@ KIFS_DEV int reduce_pio2(float x, float& r) {
     t = fmaf_(-n, P2, t);
     t = fmaf_(-n, P3, t);
     r = t;
-    float q = n - 4.0f * rint_(n * 0.25f);
-    return int(q) & 3;
+    // The quadrant is n mod 4.  The oracle writes it int(n - 4 rint(n / 4)) & 3; every caller bounds |x| by 2^20, so n
+    // is an integer below 2^20 in magnitude: n / 4, its rounding, the product and the difference are exact, the
+    // difference is congruent to n modulo 4, and the low two bits of a two's-complement integer ARE its residue
+    // modulo 4 -- int(n) & 3 is the same number for every such n, four instructions shorter.
+    return int(n) & 3;
 }
 
 KIFS_DEV float sin_kernel(float r) {
@@ -325,8 +328,17 @@ KIFS_DEV float sqrt_mid(float x) {
 
 KIFS_DEV bool log2_ordinary(float x) { return (x >= 1.17549435e-38f) && (x <= 3.40282347e38f); }  // positive normal
 KIFS_DEV float log2_core(float x) {
-    int e;
-    float m = log_reduce(x, e);
+    // log_reduce() for a NORMAL x: without split_pos' 2^23 pre-scaling of denormals -- a core's argument is ordinary
+    // by definition (quat_pow_step checks |q|^2 >= 2^-60 once per step), so the scaling selects nothing
+    const uint32_t ix = bits(x);
+    int e = int(ix >> 23) - 126;
+    float m = from_bits((ix & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
     float z = m * m;
     float y = (log_poly(m) * m) * z;
     y = fmaf_(-0.5f, z, y);
@@ -349,11 +361,12 @@ KIFS_DEV float exp2_core(float x) {
     p = fmaf_(p, r, 2.402264791363012E-001f);
     p = fmaf_(p, r, 6.931472028550421E-001f);
     p = fmaf_(p, r, 1.0f);
-    int ni = int(n);
-    int n1 = ni / 2, n2 = ni - n1;
-    float s1 = from_bits(uint32_t(n1 + 127) << 23);
-    float s2 = from_bits(uint32_t(n2 + 127) << 23);
-    return (p * s1) * s2;
+    // exp2_ scales in two exact-or-once-rounded steps, (p 2^n1) 2^n2 with n1 + n2 = n, because 2^n itself may not be a
+    // float (n = 128, n < -126).  For an ordinary argument n is in [-128, 128] and p in (0.7, 1.5): the first product
+    // is exact (a normal number), the second rounds at most once -- when the result is denormal -- or overflows to
+    // infinity: that is scalbn(p, n) by definition, which v_ldexp_f32 computes (f32 denormals are on), one instruction
+    // for eight.  tests/test_gpu_parity_points.py::test_exp2_core_scales_like_the_oracle sweeps it.
+    return __builtin_ldexpf(p, int(n));
 }
 
 KIFS_DEV bool acos_ordinary(float x) { return (x >= -1.0f) && (x <= 1.0f); }  // false for NaN

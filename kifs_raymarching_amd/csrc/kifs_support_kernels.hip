@@ -323,6 +323,11 @@ __global__ void eval_math_kernel(int fn, const float* __restrict__ in, float par
     case 9: r = rcp_mid(x); break;
     case 10: r = sqrt_mid(x); break;
     case 11: r = sin_flat(x); break;
+    case 12: r = exp2_core(x); break;
+    case 13: r = log2_core(x); break;
+    case 14: { float sn, cs; sincos_core(x, sn, cs); r = sn; break; }
+    case 15: { float sn, cs; sincos_core(x, sn, cs); r = cs; break; }
+    case 16: r = acos_core(x); break;
     default: r = x; break;
     }
     out[i] = r;

@@ -111,6 +111,34 @@ def test_elementary_functions_bit_exact(fn, oname, gs, oracle):
     assert not bad.any(), (oname, int(bad.sum()), xs[bad][:5], got[bad][:5], want[bad][:5])
 
 
+def test_straight_line_cores_equal_the_oracle_on_ordinary_arguments(gs, oracle):
+    """The cores of the generalised-Julia orbit step (kifs_device_math.hpp: exp2_core scales with one v_ldexp_f32, log2_core
+    skips the denormal pre-scaling, the sin / cos quadrant is int(n) & 3) against the oracle's full functions wherever
+    quat_pow_step lets a core's result through: |e| < 127.99999 for exp2 (every integer and half-integer neighbourhood,
+    the denormal results below -126, the overflow at 128), 2^-60 <= x < 2^60 for log2, |x| <= 10 pi and out to 2^20 for
+    sin / cos, |x| <= 1 for acos."""
+    rng = np.random.default_rng(21)
+    L = oracle.lib()
+    halves = np.arange(-128, 129, 0.5, dtype=F)
+    near = np.concatenate([np.nextafter(halves, F(-1e9)), np.nextafter(halves, F(1e9)), halves])
+    ex = np.concatenate([near, rng.uniform(-127.99999, 127.99999, 400000).astype(F),
+                         rng.uniform(-127.99999, -125.0, 50000).astype(F), rng.uniform(126.0, 127.99999, 50000).astype(F)])
+    ex = ex[np.abs(ex) < F(127.99999)]
+    lg = np.concatenate([np.exp2(rng.uniform(-60, 60, 300000)).astype(F), rng.uniform(0.4, 2.2, 100000).astype(F),
+                         np.array([2.0 ** -60, 1.0, 0.70710677, 0.70710678, 0.7071068], dtype=F)])
+    sc = np.concatenate([rng.uniform(-32, 32, 300000), rng.uniform(-1048576, 1048576, 100000),
+                         np.arange(-40, 41) * (np.pi / 2)]).astype(F)
+    ac = np.concatenate([rng.uniform(-1, 1, 300000).astype(F), np.array([1.0, -1.0, 0.5, -0.5, 0.0, -0.0], dtype=F),
+                         np.nextafter(F(0.5), F(1)).reshape(1), np.nextafter(F(-0.5), F(-1)).reshape(1)])
+    for fn, oname, xs in ((12, "kor_exp2f", ex), (13, "kor_log2f", lg), (14, "kor_sinf", sc), (15, "kor_cosf", sc),
+                          (16, "kor_acosf", ac)):
+        f = getattr(L, oname)
+        got = gs.eval_math(fn, xs)
+        want = np.array([f(float(x)) for x in xs], dtype=F)
+        bad = ~same_bits(got, want)
+        assert not bad.any(), (oname, int(bad.sum()), xs[bad][:5], got[bad][:5], want[bad][:5])
+
+
 def test_pow_bit_exact(gs, oracle):
     rng = np.random.default_rng(7)
     xs = np.concatenate([rng.uniform(0, 40, 100000), [0.0, 1.0, np.inf, np.nan, -1.0]]).astype(F)

@@ -49,6 +49,24 @@ __global__ void k(float* sink, unsigned long long* clk, float seed) {
                          "s_mov_b64 exec, s[20:21]\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                          : "v"(b), "v"(c), "s"(MODE == 5 ? 0xffffffffull : 0xffull) : "s20", "s21");
+        } else if (MODE == 7) {  // 16 v_fma_f32 in ONE dependent chain (the Sierpinski fold, a Horner polynomial)
+            asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         : "+v"(a0) : "v"(b), "v"(c));
+        } else if (MODE == 8) {  // 16 instructions in TWO interleaved dependent chains
+            asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                         "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                         "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                         "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                         : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));
+        } else if (MODE == 9) {  // the fold's own mix in one dependent chain: add, mul, min, mul, fma, fma (x2) + 4 fma
+            asm volatile("v_add_f32 %1, %0, %0\n v_mul_f32 %1, %1, %2\n v_min_f32 %1, 0, %1\n v_fma_f32 %0, %1, %2, %0\n"
+                         "v_add_f32 %1, %0, %0\n v_mul_f32 %1, %1, %2\n v_min_f32 %1, 0, %1\n v_fma_f32 %0, %1, %2, %0\n"
+                         "v_add_f32 %1, %0, %0\n v_mul_f32 %1, %1, %2\n v_min_f32 %1, 0, %1\n v_fma_f32 %0, %1, %2, %0\n"
+                         "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n"
+                         : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));
         } else if (MODE == 4) {  // 16 v_cmp + v_cndmask pairs (8 pairs)
             asm volatile("v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %2, vcc\n v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %1, %1, %2, vcc\n"
                          "v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %2, vcc\n v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %1, %1, %2, vcc\n"
@@ -68,7 +86,7 @@ void run(const char* name) {
     float* sink; unsigned long long* clk;
     hipMalloc(&sink, 4); hipMalloc(&clk, 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int wps : {1, 2, 4, 8}) {  // waves per SIMD: 256 CUs x 4 SIMDs x wps waves, as blocks of 256 threads
+    for (int wps : {1, 2, 3, 4, 5, 6, 8}) {  // waves per SIMD: 256 CUs x 4 SIMDs x wps waves, as blocks of 256 threads
         int blocks = 256 * wps;
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, sink, clk, 1.0f);
         hipEventRecord(e0, 0);
@@ -88,5 +106,6 @@ void run(const char* name) {
 int main() {
     run<0>("v_fma_f32"); run<1>("v_pk_fma_f32"); run<2>("v_pk_mul_f32"); run<3>("v_mul_f32"); run<4>("v_cmp+cndmask");
     run<5>("v_fma lanes<32"); run<6>("v_fma lanes<8");
+    run<7>("fma 1 chain"); run<8>("fma 2 chains"); run<9>("fold mix chain");
     return 0;
 }
