@@ -194,7 +194,7 @@ KIFS_DEV int reduce_pio2(float x, float& r) {
     t = fmaf_(-n, P2, t);
     t = fmaf_(-n, P3, t);
     r = t;
-    // The quadrant is n mod 4.  The oracle writes it int(n - 4 rint(n / 4)) & 3; every caller bounds |x| by 2^20, so n
+    // The quadrant is n mod 4.  The arithmetic contract writes it int(n - 4 rint(n / 4)) & 3; every caller bounds |x| by 2^20, so n
     // is an integer below 2^20 in magnitude: n / 4, its rounding, the product and the difference are exact, the
     // difference is congruent to n modulo 4, and the low two bits of a two's-complement integer ARE its residue
     // modulo 4 -- int(n) & 3 is the same number for every such n, four instructions shorter.
@@ -365,7 +365,7 @@ KIFS_DEV float exp2_core(float x) {
     // float (n = 128, n < -126).  For an ordinary argument n is in [-128, 128] and p in (0.7, 1.5): the first product
     // is exact (a normal number), the second rounds at most once -- when the result is denormal -- or overflows to
     // infinity: that is scalbn(p, n) by definition, which v_ldexp_f32 computes (f32 denormals are on), one instruction
-    // for eight.  tests/test_gpu_parity_points.py::test_exp2_core_scales_like_the_oracle sweeps it.
+    // for eight.  tests/test_gpu_parity_points.py::test_straight_line_cores_... sweeps it against the contract's exp2.
     return __builtin_ldexpf(p, int(n));
 }
 

@@ -53,9 +53,9 @@ constexpr double PAIR_FROM_GENJULIA = 12000.0;  // generalised Julia (1080p x32 
 constexpr double PAIR_FROM_LONE_KIFS = 12000.0; // a big lone KIFS frame (1440p Sierpinski at distance 2: -11 %)
 // the bunny (tools/sweep_bunny_coop.sh -> profiles/r03/sweep_bunny_coop.txt; 1080p at distance 5 is 149 heavy tiles a frame):
 constexpr double BUNNY_ROUNDS_FROM = 450.0;   // below: whole rays, four lanes per pixel (x2: 0.421 against 0.528 ms; x4: 0.592 against 0.536)
-constexpr double BUNNY_PAIR_FROM = 1800.0;    // two tiles per workgroup (x8: 25.7 -> 23.4 Gpixel/s; x16: 28.3 -> 35.9)
+constexpr double BUNNY_PAIR_FROM = 1600.0;    // two tiles per workgroup (r04, chunks drawn by ticket: x8 28.3 -> 25.4 Gpixel/s; x12 30.4 -> 33.0; x16 30.0 -> 39.1)
 constexpr int ROUND_STEPS_BUNNY_COOP = 4;     // its rounds (x48: 1/2/3/4/6/8 steps -> 52.2/53.6/53.8/53.5/53.3/52.8 Gpixel/s; the lanes-per-ray form: 4-8 alike)
-constexpr double BUNNY_COOP_FROM = 3500.0;    // four waves per 64 rays (x16: 35.9 against 30.4; x24: 37.4 / 37.2; x32: 36.7 / 44.4; x48: 37.4 / 51.8)
+constexpr double BUNNY_COOP_FROM = 4000.0;    // four waves per 64 rays (r04, profiles/r04/sweep_bunny_shapes.txt: x16 39.1 against 29.1; x24 40.7 / 38.7; x32 40.1 / 48.4; x48 58.2)
 }  // namespace rules
 
 int tuning_knob(const char* name) {

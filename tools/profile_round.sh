@@ -11,13 +11,15 @@ cd $R
 python bench.py > $O/cfg2_bench.json
 echo "bench default done"
 : > $O/other_workloads_bench.jsonl
-for w in cfg1_julia_256 cfg3_sierpinski_1080p cfg4_julia_4096 ref_julia_1080p n1_genjulia_1080p n2_bunny_1080p; do
+[ -n "$KIFS_PROFILE_QUICK" ] && SWEEP="" || SWEEP="cfg1_julia_256 cfg3_sierpinski_1080p cfg4_julia_4096 ref_julia_1080p n1_genjulia_1080p n2_bunny_1080p"
+for w in $SWEEP; do
   for b in 48 8 1; do
     python bench.py --workload $w --steps 100 --warmup 12 --cpu-seconds $([ $b = 48 ] && echo 4 || echo 0) --no-secondary --frames-per-launch $b >> $O/other_workloads_bench.jsonl
   done
   echo "bench $w done"
 done
-for w in cfg5_sierpinski_8k_orbit cfg5_sierpinski_8k_orbit_shadows; do
+[ -n "$KIFS_PROFILE_QUICK" ] && SWEEP5="" || SWEEP5="cfg5_sierpinski_8k_orbit cfg5_sierpinski_8k_orbit_shadows"
+for w in $SWEEP5; do
   python bench.py --workload $w --steps 40 --warmup 6 --cpu-seconds 0 --no-secondary --frames-per-launch 1 >> $O/other_workloads_bench.jsonl
   python bench.py --workload $w --steps 12 --warmup 3 --cpu-seconds 0 --no-secondary --frames-per-launch 4 >> $O/other_workloads_bench.jsonl
   # the workload as BASELINE.json names it: the WHOLE 120-frame orbit, every frame resident (15.9 GB), per launch size
