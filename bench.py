@@ -1258,12 +1258,14 @@ def main():
                               "8-row stripes dealt round-robin"
                               + (f", rank 0 : peer = {root_weight[0]} : {root_weight[1]}" if root_weight[0] != root_weight[1] else ""))
                            + f") of {frames_per_step} frames per step, gathered into rank 0's frames by grouped "
-                           "RCCL point-to-point over xGMI"
+                           + ("RCCL point-to-point over xGMI" if args.backend == "nccl" else
+                              "point-to-point transfers (REHEARSAL: gloo, staged through the host; RCCL needs a GPU per rank)")
                            + (": peers send the 32x8 tiles that hold something, rank 0 fills in the background"
                               if args.gather == "sparse" else " + stripe unpack"))
         else:
             parallelism = (f"{world} GPUs x whole frames (frame-parallel, {B} per launch), one process per GPU, "
-                           + ("finished frames sent to rank 0 by grouped RCCL p2p" if args.deliver == "root"
+                           + (("finished frames sent to rank 0 by grouped RCCL p2p" if args.backend == "nccl" else
+                               "finished frames sent to rank 0 (rehearsal: gloo)") if args.deliver == "root"
                               else "frames stay on the GPU that rendered them (no exchange step)"))
         out = {
             "metric": METRIC,

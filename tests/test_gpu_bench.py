@@ -92,7 +92,7 @@ def test_two_ranks_are_started_by_bench_itself_and_gather_exact_frames():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["gathered_frame_equals_single_gpu_frame"] is True
     cfg = d["config"]
-    assert cfg["frames_per_step"] == 8 and "8-row stripes" in cfg["parallelism"] and "RCCL" in cfg["parallelism"]
+    assert cfg["frames_per_step"] == 8 and "8-row stripes" in cfg["parallelism"] and "REHEARSAL: gloo" in cfg["parallelism"]
     assert cfg["root_weight"] >= 1 and cfg["peer_weight"] >= 1 and sum(cfg["rows_per_rank"]) == 1080
     trial = cfg["root_weight_calibration"]["ms_per_step_by_share"]
     assert "1:1" in trial and len(trial) >= 3 and all(v > 0 for v in trial.values())
