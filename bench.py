@@ -693,6 +693,10 @@ def main():
             with socket.socket() as s_:
                 s_.bind(("127.0.0.1", 0))
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]))
+        # One node, rendezvous on the loopback address: gloo (the rehearsal backend, and the CPU side group of the RCCL
+        # run) would otherwise pick its interface by resolving the hostname, which a container need not be able to do.
+        if os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost") and os.path.exists("/sys/class/net/lo"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
