@@ -1,6 +1,6 @@
 // The asm statement of julia_fast_march (kifs_scene.hpp), included once per variant with
 // KIFS_JULIA_DIVSQRT / KIFS_JULIA_DIVSQRT_OUT_OF_LINE, KIFS_FAST_TRIP / KIFS_TRIP_EXIT / KIFS_TRIP_EXIT_BACK / KIFS_JULIA_PROLOGUE /
-// KIFS_JULIA_C_OPERANDS defined by the includer.  See the
+// KIFS_JULIA_C_OPERANDS / KIFS_ORBIT_LOOP / KIFS_ORBIT_LOOP_OUT_OF_LINE defined by the includer.  See the
 // register map and the description there.
     asm volatile(
         "s_mov_b64 s[84:85], exec\n"
@@ -29,17 +29,7 @@
         "s_mov_b32 s96, %[blocks]\n"
         "s_cmp_lg_u32 %[rem], 0\n"
         "s_cbranch_scc1 30f\n"                                // trip count not a multiple of 6 (out of line)
-        "12:\n"
-        "s_cmp_eq_u32 s96, 0\n"
-        "s_cbranch_scc1 14f\n"
-        "13:\n"
-        KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP
-        "s_cbranch_execz 14f\n"
-        KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP KIFS_TRIP_EXIT KIFS_FAST_TRIP
-        "s_cbranch_execz 14f\n"
-        "s_sub_u32 s96, s96, 1\n"
-        "s_cmp_lg_u32 s96, 0\n"
-        "s_cbranch_scc1 13b\n"
+        KIFS_ORBIT_LOOP                                       // blocks of six trips from label 12, falls out at 14
         "14:\n"
         "s_mov_b64 exec, s[86:87]\n"
         // |q|^2 must be a positive normal number for the short log; otherwise hand the step back
@@ -98,6 +88,7 @@
         "18:\n"                                               // nobody left, or out of iterations
         "s_mov_b64 %[live], 0\n"
         "s_branch 20f\n"
+        KIFS_ORBIT_LOOP_OUT_OF_LINE
         // ---- remainder trips (sdf_iters % 6), out of the hot line
         "30:\n"
         "s_mov_b32 s97, %[rem]\n"

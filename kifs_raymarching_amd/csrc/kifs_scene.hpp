@@ -592,6 +592,47 @@ KIFS_DEV float soft_shadow(const FrameParams& P, V3 p, V3 n, bool lanes_hit, Sdf
     "v_fma_f32 v45, v32, v32, -v48\n"                                                        \
     "v_add_f32_e32 v45, %[cx], v45\n"
 
+// The loop over blocks of six trips (s96 = blocks left; label 12 in, label 14 out), two forms:
+//  * SINGLE: one block per pass -- the throughput kernel's (its SIMDs hold several busy waves: a taken branch is
+//    hidden, the code it fetches is not: two blocks per pass cost the headline 0.4 %).
+//  * PAIRED: two blocks per pass, an odd block left over out of line (labels 16 / 17) -- the latency kernels': a lone
+//    wave pays for every taken branch, and with one block per pass the reference's 100 iterations took the back edge
+//    sixteen times per march step (lone 1080p frame at the reference's constants 0.218 -> 0.210 ms, the headline
+//    workload's 12 iterations 0.1557 -> 0.1546; profiles/r04/ab_paired_blocks.txt).
+#define KIFS_ORBIT_BLOCK_(exit)                                                             \
+    KIFS_FAST_TRIP exit KIFS_FAST_TRIP exit KIFS_FAST_TRIP
+#define KIFS_ORBIT_LOOP_SINGLE                                                              \
+    "12:\n"                                                                                 \
+    "s_cmp_eq_u32 s96, 0\n"                                                                 \
+    "s_cbranch_scc1 14f\n"                                                                  \
+    "13:\n"                                                                                 \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT) "s_cbranch_execz 14f\n"                               \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT) "s_cbranch_execz 14f\n"                               \
+    "s_sub_u32 s96, s96, 1\n"                                                               \
+    "s_cmp_lg_u32 s96, 0\n"                                                                 \
+    "s_cbranch_scc1 13b\n"
+#define KIFS_ORBIT_LOOP_PAIRED                                                              \
+    "12:\n"                                                                                 \
+    "s_cmp_lt_u32 s96, 2\n"                                                                 \
+    "s_cbranch_scc1 16f\n"                                                                  \
+    "13:\n"                                                                                 \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT) "s_cbranch_execz 14f\n"                               \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT) "s_cbranch_execz 14f\n"                               \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT) "s_cbranch_execz 14f\n"                               \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT) "s_cbranch_execz 14f\n"                               \
+    "s_sub_u32 s96, s96, 2\n"                                                               \
+    "s_cmp_gt_u32 s96, 1\n"                                                                 \
+    "s_cbranch_scc1 13b\n"                                                                  \
+    "s_cmp_lg_u32 s96, 0\n"                                                                 \
+    "s_cbranch_scc1 17f\n" /* one block left (out of line) */
+#define KIFS_ORBIT_LOOP_PAIRED_OUT_OF_LINE                                                  \
+    "16:\n"                                                                                 \
+    "s_cmp_eq_u32 s96, 0\n"                                                                 \
+    "s_cbranch_scc1 14b\n"                                                                  \
+    "17:\n"                                                                                 \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT_BACK) "s_cbranch_execz 14b\n"                          \
+    KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT_BACK) "s_branch 14b\n"
+
 // quot = |q|^2 / dqs and root = sqrt(quot), both correctly rounded, any operands: the sequences
 // hipcc emits (v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup; v_sqrt + one-ulp fixup
 // with the 2^32 pre-scaling for tiny arguments), with their wait states.  v44 = |q|^2, v53 = dqs,
@@ -683,6 +724,8 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 #define KIFS_TRIP_EXIT "s_cbranch_execz 14f\n"  /* scalar slots are free where the vector pipe is the limit: test every trip */
 #define KIFS_TRIP_EXIT_BACK "s_cbranch_execz 14b\n"  /* the same from the remainder trips, which sit BEHIND label 14 */
 #define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_SCALAR
+#define KIFS_ORBIT_LOOP KIFS_ORBIT_LOOP_SINGLE
+#define KIFS_ORBIT_LOOP_OUT_OF_LINE
 #define KIFS_JULIA_C_OPERANDS [cy] "s"(P.c.y), [cz] "s"(P.c.z), [cw] "s"(P.c.w), [cx] "s"(P.c.x)
         if constexpr (SHORT_DIVSQRT) {
 #define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_ORDINARY
@@ -701,6 +744,8 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 #undef KIFS_TRIP_EXIT
 #undef KIFS_TRIP_EXIT_BACK
 #undef KIFS_JULIA_PROLOGUE
+#undef KIFS_ORBIT_LOOP
+#undef KIFS_ORBIT_LOOP_OUT_OF_LINE
 #undef KIFS_JULIA_C_OPERANDS
     } else {
         const F2 cyz{P.c.y, P.c.z}, cw0{P.c.w, 0.0f}, c0x{0.0f, P.c.x};
@@ -708,6 +753,8 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 #define KIFS_TRIP_EXIT  /* a lone wave pays for every instruction: test every third trip only */
 #define KIFS_TRIP_EXIT_BACK
 #define KIFS_JULIA_PROLOGUE KIFS_JULIA_PROLOGUE_PACKED
+#define KIFS_ORBIT_LOOP KIFS_ORBIT_LOOP_PAIRED
+#define KIFS_ORBIT_LOOP_OUT_OF_LINE KIFS_ORBIT_LOOP_PAIRED_OUT_OF_LINE
 #define KIFS_JULIA_C_OPERANDS [cyz] "s"(cyz), [cw0] "s"(cw0), [c0x] "s"(c0x)
         if constexpr (SHORT_DIVSQRT) {
 #define KIFS_JULIA_DIVSQRT KIFS_DIVSQRT_ORDINARY
@@ -726,6 +773,8 @@ KIFS_DEV void julia_fast_march(const FrameParams& P, V3 dir, float& t, V3& p, bo
 #undef KIFS_TRIP_EXIT
 #undef KIFS_TRIP_EXIT_BACK
 #undef KIFS_JULIA_PROLOGUE
+#undef KIFS_ORBIT_LOOP
+#undef KIFS_ORBIT_LOOP_OUT_OF_LINE
 #undef KIFS_JULIA_C_OPERANDS
     }
     const unsigned lane = __lane_id();

@@ -175,19 +175,24 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
             s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cam, gui))
             want = oracle.render(s, c, o, oracle.iters(*iters), y0=y0, y1=y1, ext=ext)
             if scene.startswith("bunny"):
-                # the bunny's throughput path has three forms, chosen by the launch's load (kifs_schedule.cpp): four
-                # lanes per ray with one or two tiles per workgroup, four waves per 64 rays from ~3500 heavy tiles
-                for views, kernel, tiles in ((2, "render_group_kernel", 1), (3, "render_group_kernel", 2),
-                                             (5, "render_bunny_coop_kernel", 2)):
+                # the bunny's throughput path has three forms, chosen by the launch's load (kifs_schedule.cpp, rules::BUNNY_*:
+                # disc tiles x views): four lanes per ray with one tile per workgroup (a farther camera: ~700 heavy tiles
+                # in two views) or two (from 1600), four waves per 64 rays from 4000
+                far = kifs.CameraData(origin_distance=3.2, phi=0.9, theta=0.35)
+                s_f, c_f, o_f = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, far, gui))
+                want_far = oracle.render(s_f, c_f, o_f, oracle.iters(*iters), y0=y0, y1=y1, ext=ext)
+                for view_cam, view_want, views, kernel, tiles in ((far, want_far, 2, "render_group_kernel", 1),
+                                                                  (cam, want, 2, "render_group_kernel", 2),
+                                                                  (cam, want, 5, "render_bunny_coop_kernel", 2)):
                     outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(views)]
                     st = torch.cuda.Stream()
-                    gs.render_batch_async(outs, [cam] * views, stream=st, y0=y0, y1=y1)
+                    gs.render_batch_async(outs, [view_cam] * views, stream=st, y0=y0, y1=y1)
                     st.synchronize()
                     assert (gs.debug_last_kernel(), gs.debug_last_group_tiles()) == (kernel, tiles), (scene, views)
                     got = outs[-1].cpu().numpy()
                     for o in outs[:-1]:
                         assert (o.cpu().numpy() == got).all()
-                    assert diff_report(got, want)["mismatched_pixels"] == 0, (scene, y0, y1, views)
+                    assert diff_report(got, view_want)["mismatched_pixels"] == 0, (scene, y0, y1, views)
             elif batched:  # a batch of two is never residency-capped
                 outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
                 st = torch.cuda.Stream()

@@ -65,15 +65,23 @@ def instruction_counts(short_divsqrt=True):
 
     def segment(a, b):
         """Instruction lines between the line holding `a` and the line holding `b` (exclusive)."""
-        hit = lambda pat, l: (l.strip() == pat) if pat.startswith("KIFS_") else (pat in l)  # macros: whole code lines only
+        # macros: code lines that START with the name (a comment may follow), not mentions inside comments
+        hit = lambda pat, l: bool(re.match(re.escape(pat) + r"(\s|$)", l.strip())) if pat.startswith("KIFS_") else (pat in l)
         ia = next(i for i, l in enumerate(asm) if hit(a, l))
         ib = next(i for i, l in enumerate(asm) if hit(b, l) and i > ia)
         return _count(asm[ia + 1:ib])
     head = segment('"10:\\n"', "KIFS_JULIA_PROLOGUE")            # dot(p,p), bound test, exec, branch
-    enter = segment("KIFS_JULIA_PROLOGUE", '"12:\\n"')          # exec save, trip counters, remainder branch
-    loop_head = segment('"12:\\n"', '"13:\\n"')                 # s_cmp, s_cbranch
-    loop_tail = 3                                               # s_sub, s_cmp, s_cbranch at the end of a block of six
-    exit_tests = 2                                              # the two s_cbranch_execz inside a block (every third trip)
+    enter = segment("KIFS_JULIA_PROLOGUE", "KIFS_ORBIT_LOOP")   # exec save, trip counters, remainder branch
+    # the latency kernels' loop over blocks of six trips (KIFS_ORBIT_LOOP_PAIRED, kifs_scene.hpp): two blocks per pass
+    paired = _macro(scene, "KIFS_ORBIT_LOOP_PAIRED")
+    assert sum("KIFS_ORBIT_BLOCK_(KIFS_TRIP_EXIT)" in l for l in paired) == 4, "two blocks of six trips (four halves) per pass"
+    i13 = next(i for i, l in enumerate(paired) if '"13:' in l)
+    loop_head = _count(paired[:i13])                            # s_cmp, s_cbranch in front of the loop
+    exit_tests = 2                                              # the two s_cbranch_execz of a block (every third trip)
+    after_blocks = _count(paired[i13:])                         # behind the pair of blocks: 3 for the back edge + 2 for the odd block
+    # (the blocks' own lines start with the block macro, not with a quote: they are counted through `trip` and `exit_tests`)
+    loop_tail = 3
+    assert after_blocks == loop_tail + 2, after_blocks
     rem_each = 3                                                # s_sub, s_cmp, s_cbranch per remainder trip (label 31)
     after = segment('"14:\\n"', "KIFS_JULIA_DIVSQRT")           # exec restore, class test, log
     finish = segment("KIFS_JULIA_DIVSQRT", '"41:\\n"')          # d = 0.25 lg * root; or-exec, outside test
@@ -88,12 +96,15 @@ def instruction_counts(short_divsqrt=True):
 
 
 def step_model(ic, sdf_iters):
-    """(I_in without trips, I_trip, I_out): a step's instructions as fixed + per-trip parts.  A trip that is one of a
-    block of six shares the block's 2 exit tests and 3 loop instructions (5 / 6 per trip); a remainder trip (sdf_iters
-    mod 6) carries 3 of its own.  The fixed parts do not depend on the ray."""
+    """(I_in without trips, I_trip, I_out): a step's instructions as fixed + per-trip parts: the orbit loop's own
+    instructions (exit tests, counters, branches) are spread over the trips of a full-length orbit; a remainder trip
+    (sdf_iters mod 6) carries 3 of its own.  The fixed parts do not depend on the ray."""
     rem = sdf_iters % 6
     blocks = sdf_iters // 6
-    per_trip = ic["trip"] + ((ic["exit_tests_per_block"] + ic["loop_tail"]) * blocks + ic["remainder_overhead_per_trip"] * rem) / max(1, sdf_iters)
+    # two blocks per pass of the loop: 3 loop instructions per pair, 2 more when the loop is left (is a block left over?),
+    # 1 for the odd block's way back; 2 exit tests per block; 3 per remainder trip
+    loop = ic["exit_tests_per_block"] * blocks + ic["loop_tail"] * (blocks // 2) + (2 if blocks >= 2 else 0) + (blocks % 2)
+    per_trip = ic["trip"] + (loop + ic["remainder_overhead_per_trip"] * rem) / max(1, sdf_iters)
     i_in = ic["head"] + ic["prologue"] + ic["enter"] + ic["loop_head"] + ic["after_orbit"] + ic["divsqrt"] + ic["finish"] + ic["advance"]
     i_out = ic["head"] + 3 + ic["outside_block"] + ic["outside_sqrt"] + ic["outside_tail"] + ic["advance"]
     return i_in, per_trip, i_out

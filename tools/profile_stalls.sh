@@ -20,6 +20,7 @@ PC="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 for item in $LIST; do
   w=${item%@*}; b=${item#*@}
   D=$O/$item; rm -rf $D; mkdir -p $D
+  cp $O/srchash.txt $D/srchash.txt  # (the summaries skip directories left over from another library's run)
   B="$R/bench.py --workload $w --frames-per-launch $b --cpu-seconds 0 --no-secondary --settle-ms 20 --steps 16 --warmup 4"
   rocprofv3 --pmc $PA -d $D/pmc_a -o t --output-format csv -- python3 $B > $D/pmc_a.log 2>&1
   rocprofv3 --pmc $PB -d $D/pmc_b -o t --output-format csv -- python3 $B > $D/pmc_b.log 2>&1

@@ -56,12 +56,22 @@ def per_dispatch(path):
     return out, meta
 
 
+
+def same_run(src, d):
+    """Is directory `d` from the run whose stamp lies in `src` (gpurun merges a call's files INTO gpurun_out/: the
+    directories of earlier rounds' runs stay where they were)?"""
+    a, b = Path(src) / "srchash.txt", Path(d) / "srchash.txt"
+    return a.exists() and b.exists() and a.read_text() == b.read_text()
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
     dst = ROOT / "profiles" / rnd
     dst.mkdir(parents=True, exist_ok=True)
     summary = {}
     for d in sorted(p for p in SRC.iterdir() if p.is_dir() and "@" in p.name):
+        if not same_run(SRC, d):
+            print(f"(skipped {d.name}: left over from another run)", file=sys.stderr)
+            continue
         c, meta = {}, {}
         for p in ("pmc_a", "pmc_b", "pmc_c"):
             hits = sorted((d / p).rglob("*counter_collection.csv"))

@@ -11,7 +11,7 @@ O=$R/gpurun_out/prof_wl
 mkdir -p $O
 LIST="$@"
 [ -z "$LIST" ] && LIST="cfg2_julia_1080p@48 cfg3_sierpinski_1080p@48 cfg4_julia_4096@48 ref_julia_1080p@48 \
-n1_genjulia_1080p@48 n2_bunny_1080p@48 cfg5_sierpinski_8k_orbit@8 cfg5_sierpinski_8k_orbit_shadows@8 cfg1_julia_256@48"
+n1_genjulia_1080p@48 n2_bunny_1080p@48 n2_bunny_1080p@8 cfg2_julia_1080p@8 cfg5_sierpinski_8k_orbit@8 cfg5_sierpinski_8k_orbit_shadows@8 cfg1_julia_256@48"
 cp $R/kifs_raymarching_amd/libkifs_hip.so.srchash $O/srchash.txt  # which library the counters belong to
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
@@ -19,6 +19,7 @@ for item in $LIST; do
   w=${item%@*}; b=${item#*@}
   case $w in cfg5*|cfg4*) steps=8; warm=3;; *) steps=24; warm=6;; esac
   D=$O/$item; rm -rf $D; mkdir -p $D
+  cp $O/srchash.txt $D/srchash.txt  # (the summaries skip directories left over from another library's run)
   B="$R/bench.py --workload $w --frames-per-launch $b --cpu-seconds 0 --no-secondary --settle-ms 20"
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o t -- python3 $B --steps $((steps * 4)) --warmup $warm > $D/trace.log 2>&1
   rocprofv3 --pmc $SQ -d $D/pmc_sq -o t --output-format csv -- python3 $B --steps $steps --warmup $warm > $D/pmc_sq.log 2>&1

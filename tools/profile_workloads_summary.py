@@ -69,6 +69,13 @@ def per_dispatch(path, kernel_prefix):
     return out, meta
 
 
+
+def same_run(src, d):
+    """Is directory `d` from the run whose stamp lies in `src` (gpurun merges a call's files INTO gpurun_out/: the
+    directories of earlier rounds' runs stay where they were)?"""
+    a, b = Path(src) / "srchash.txt", Path(d) / "srchash.txt"
+    return a.exists() and b.exists() and a.read_text() == b.read_text()
+
 def main():
     from kifs_raymarching_amd.configs import WORKLOADS  # (imports the package: needs the built library)
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
@@ -78,6 +85,9 @@ def main():
     traffic = json.loads(traffic_path.read_text()) if traffic_path.exists() else {}
     summary = {}
     for d in sorted(p for p in SRC.iterdir() if p.is_dir() and "@" in p.name):
+        if not same_run(SRC, d):
+            print(f"(skipped {d.name}: left over from another run)", file=sys.stderr)
+            continue
         name, B = d.name.split("@")
         B = int(B)
         w = WORKLOADS[name]
