@@ -49,7 +49,9 @@ constexpr double WAVE_FROM_JULIA = 12500.0;   //   batched Julia (1080p x32: 1.1
 constexpr double WAVE_FROM_OTHER = 32000.0;   //   everything else (8K Sierpinski x4 +16 %)
 constexpr double PAIR_FROM_BATCH = 3500.0;    // two tiles per 256-thread workgroup: batches (1080p Julia 0.319 -> 0.281 ms;
                                               //   below it pairing halves the workgroups side by side: 720p x8 0.222 -> 0.188 with one)
-constexpr double PAIR_FROM_GENJULIA = 12000.0;  // generalised Julia (1080p x32 0.140 -> 0.125 ms per frame; x8 nothing)
+constexpr double PAIR_FROM_GENJULIA = 5000.0;   // generalised Julia (r04, chunks drawn by ticket: x4 8.9 -> 8.0 Gpixel/s, x8 13.4 / 13.5, x12 15.8 -> 16.4,
+                                                //   x16 17.7 -> 19.4, x24 19.4 -> 22.4; 12 000 until then)          (tools/sweep_group_shapes.sh)
+constexpr double PAIR_FROM_BATCH_KIFS = 7000.0; // KIFS scenes (r04: 1080p Sierpinski x8 43.4 with one tile against 42.2 with two, x16 54.6 / 61.7)
 constexpr double PAIR_FROM_LONE_KIFS = 12000.0; // a big lone KIFS frame (1440p Sierpinski at distance 2: -11 %)
 // the bunny (tools/sweep_bunny_coop.sh -> profiles/r03/sweep_bunny_coop.txt; 1080p at distance 5 is 149 heavy tiles a frame):
 constexpr double BUNNY_ROUNDS_FROM = 450.0;   // below: whole rays, four lanes per pixel (x2: 0.421 against 0.528 ms; x4: 0.592 against 0.536)
@@ -594,8 +596,11 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         const bool kifs_scene = group_id == uint32_t(kifs::GROUP_KIFS);
         const double wave_from = lone ? rules::WAVE_FROM_LONE : (julia ? rules::WAVE_FROM_JULIA : rules::WAVE_FROM_OTHER);
         int shape = 1;
-        if (load >= wave_from && !genjulia) shape = 0;
-        else if (!lone && load >= (genjulia ? rules::PAIR_FROM_GENJULIA : rules::PAIR_FROM_BATCH)) shape = 2;
+        // (one wave per tile needs views to interleave: TWO frames of 4096^2 -- 19 600 heavy tiles, past WAVE_FROM_JULIA -- run
+        // 31.5 Gpixel/s that way against 42.8 with pairs, four 52.0 against 44.0: r04, profiles/r04/sweep_group_shapes.txt)
+        if (load >= wave_from && !genjulia && (count >= 3 || load >= rules::WAVE_FROM_LONE)) shape = 0;
+        else if (!lone && load >= (genjulia ? rules::PAIR_FROM_GENJULIA : kifs_scene ? rules::PAIR_FROM_BATCH_KIFS : rules::PAIR_FROM_BATCH))
+            shape = 2;
         else if (lone && kifs_scene && load >= rules::PAIR_FROM_LONE_KIFS) shape = 2;
         if (forced >= 0) shape = forced;
         P.bunny_coop = 0;
