@@ -430,6 +430,9 @@ enum KifsKernel {
     KIFS_KERNEL_BUNNY_COOP = 4   /* render_bunny_coop_kernel: rays re-queued, four waves per 64 rays */
 };
 int kifs_debug_last_kernel(kifs_ctx* ctx);
+/* The bunny's throughput form in the context's latest launch: 0 = four lanes per ray with every weight in VGPRs, 1 = four
+ * waves per 64 rays, 2 = four lanes per ray with layer 2 of the network in LDS; -1 = not a re-queued bunny launch. */
+int kifs_debug_last_bunny_form(kifs_ctx* ctx);
 /* Tuning hooks: read / replace the order in which workgroups take the tiles of the full
  * frame (a permutation of (tile_x | tile_y << 16)); the order only affects speed. */
 int kifs_debug_get_tile_order(kifs_ctx* ctx, uint32_t* order, size_t max_count, size_t* count);

@@ -130,6 +130,7 @@ SIGNATURES = {
     "kifs_debug_last_round_steps": (C.c_int, [_ctx]),
     "kifs_debug_last_group_tiles": (C.c_int, [_ctx]),
     "kifs_debug_last_kernel": (C.c_int, [_ctx]),
+    "kifs_debug_last_bunny_form": (C.c_int, [_ctx]),
     "kifs_profile_read": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "kifs_strerror": (C.c_char_p, [C.c_int]),
     "kifs_abi_version": (C.c_int, []),

@@ -237,6 +237,7 @@ int kifs_debug_last_round_steps(kifs_ctx* c) { return c ? c->last_round_steps : 
 
 int kifs_debug_last_group_tiles(kifs_ctx* c) { return c ? c->last_group_tiles : -2; }
 int kifs_debug_last_kernel(kifs_ctx* c) { return c ? c->last_kernel : -2; }
+int kifs_debug_last_bunny_form(kifs_ctx* c) { return c ? c->last_bunny_form : -2; }
 
 int kifs_set_frames_in_flight(kifs_ctx* c, int n) {
     if (!c || n < 1) return KIFS_ERR_BAD_ARG;

@@ -18,19 +18,38 @@ namespace kifs {
 // ~700 instructions per lane; every value is produced by the same operation sequence as in
 // bunny_sdf, so the result is bit-identical.  The four lanes of a quad carry identical ray
 // state, which keeps all control flow quad-uniform (DPP never reads an inactive lane).
-struct BunnyQuad {  // the weights of column group j, resident in VGPRs
-    float w0[16], w1[4][16], b1[4], w2[4][16], b2[4], wo[4];
+// W2LDS: layer 2's 64 weights per column group stay in the workgroup's LDS (1 KB for the four groups, staged once by
+// bunny_w2_stage) instead of VGPRs: 216 -> 168 registers, THREE waves per SIMD instead of two, for sixteen 128-bit LDS
+// reads per estimate, four at a time.  A throughput form: the reads lengthen a lone wave's chain (1 to 12 frames of 1080p
+// per launch: -11 to -14 %), the third wave pays from ~18 frames (x20 40.1 -> 44.4 Gpixel/s, x24 40.6 -> 49.0, x32 39.9 ->
+// 49.1: profiles/r04/sweep_bunny_w2lds.txt) until the four-waves form takes over (x40 50.0 against 55.0).  Round 3 had tried
+// ALL 156 weights in LDS: 39 reads per estimate, LDS-port-bound, slower everywhere.  Same operations on the same values.
+template <bool W2LDS>
+struct BunnyQuadT {  // the weights of column group j, resident in VGPRs
+    float w0[16], w1[4][16], b1[4];
+    float w2[W2LDS ? 1 : 4][16];  // (W2LDS: unused; layer 2 is read through `w2_lds`)
+    const float* w2_lds;          // W2LDS: this lane's column group of layer 2 in LDS, [4][16]
+    float b2[4], wo[4];
 };
+using BunnyQuad = BunnyQuadT<false>;
 
-KIFS_DEV void bunny_quad_load(BunnyQuad& W, int j) {
+// Layer 2 of all four column groups into the workgroup's LDS (256 floats, one per thread of a 256-thread workgroup);
+// the caller's next barrier publishes it.
+KIFS_DEV void bunny_w2_stage(float* s_w2, int tid) {
+    if (tid < 256) s_w2[tid] = (&KIFS_BUNNY_L2[0][0][0])[tid];
+}
+
+template <bool W2LDS>
+KIFS_DEV void bunny_quad_load(BunnyQuadT<W2LDS>& W, int j, const float* s_w2 = nullptr) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) W.w0[e] = KIFS_BUNNY_L0[j][e];
+    W.w2_lds = W2LDS ? s_w2 + 64 * j : nullptr;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             W.w1[m][e] = KIFS_BUNNY_L1[j][m][e];
-            W.w2[m][e] = KIFS_BUNNY_L2[j][m][e];
+            if constexpr (!W2LDS) W.w2[m][e] = KIFS_BUNNY_L2[j][m][e];
         }
     }
 #pragma unroll
@@ -61,7 +80,8 @@ KIFS_DEV void eval_count(int slot, unsigned long long v) {
 // (Tried, r03: a `lanes` mask as in genjulia_sdf, so that a ray that has stopped inside the unit ball does not keep its wave
 // evaluating the network -- lone frame 0.376 -> 0.420 ms, 8 per launch 25.7 -> 25.3, 48 per launch 55.8 -> 55.2 Gpixel/s: the
 // lane test costs more than the evaluations it saves.)
-KIFS_DEV float bunny_sdf_quad(const BunnyQuad& W, V3 p) {
+template <bool W2LDS>
+KIFS_DEV float bunny_sdf_quad(const BunnyQuadT<W2LDS>& W, V3 p) {
 #ifdef KIFS_EVAL_COUNT
     eval_count(2, 1);
     eval_count(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) / 4);
@@ -79,10 +99,24 @@ KIFS_DEV float bunny_sdf_quad(const BunnyQuad& W, V3 p) {
     a = add4(a, mat4_vec(W.w1[3], quad_lane4<3>(f0)));
     a = add4(a, ld4(W.b1));
     const V4 f1 = add4(sin4_flat(a), f0);
-    a = mat4_vec(W.w2[0], quad_lane4<0>(f1));
-    a = add4(a, mat4_vec(W.w2[1], quad_lane4<1>(f1)));
-    a = add4(a, mat4_vec(W.w2[2], quad_lane4<2>(f1)));
-    a = add4(a, mat4_vec(W.w2[3], quad_lane4<3>(f1)));
+    if constexpr (W2LDS) {
+        // opaque per estimate and per matrix: the sixteen reads stay reads, four at a time (hoisted out of the march they
+        // are 64 VGPRs again; issued all at once, 64 temporaries) -- each matrix's address is tied to the sum before it
+        const float* w2 = W.w2_lds;
+        asm volatile("" : "+v"(w2));
+        a = mat4_vec(w2, quad_lane4<0>(f1));
+        asm volatile("" : "+v"(w2), "+v"(a.x));
+        a = add4(a, mat4_vec(w2 + 16, quad_lane4<1>(f1)));
+        asm volatile("" : "+v"(w2), "+v"(a.x));
+        a = add4(a, mat4_vec(w2 + 32, quad_lane4<2>(f1)));
+        asm volatile("" : "+v"(w2), "+v"(a.x));
+        a = add4(a, mat4_vec(w2 + 48, quad_lane4<3>(f1)));
+    } else {
+        a = mat4_vec(W.w2[0], quad_lane4<0>(f1));
+        a = add4(a, mat4_vec(W.w2[1], quad_lane4<1>(f1)));
+        a = add4(a, mat4_vec(W.w2[2], quad_lane4<2>(f1)));
+        a = add4(a, mat4_vec(W.w2[3], quad_lane4<3>(f1)));
+    }
     a = add4(a, ld4(W.b2));
     const V4 sn = sin4_flat(a);
     const V4 f2{sn.x / 1.4f + f1.x, sn.y / 1.4f + f1.y, sn.z / 1.4f + f1.z, sn.w / 1.4f + f1.w};

@@ -67,6 +67,7 @@ struct kifs_ctx {
     int last_round_steps = 0;  // kifs_debug_last_round_steps
     int last_group_tiles = -1; // kifs_debug_last_group_tiles
     int last_kernel = -1;      // kifs_debug_last_kernel
+    int last_bunny_form = -1;  // kifs_debug_last_bunny_form
     float h_srgb[256] = {};    // host copy of the sRGB threshold table (d_srgb)
     // per-launch profiling ring (kifs_set_profiling)
     bool profiling = false;

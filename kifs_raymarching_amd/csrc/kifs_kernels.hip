@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const BatchParams B) {
 //   A ray's own arithmetic is unchanged (t, and p = fma(t, dir, origin) rebuilt from it exactly as
 //   the march itself does), all rays of the workgroup make their k-th step in the same round (the
 //   step counter stays uniform), and pixels do not interact: same pixels as render_kernel.
-template <int GROUP, int PRIM, int T>
+template <int GROUP, int PRIM, int T, bool W2LDS = false>
 __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B) {
     constexpr uint32_t CAP = uint32_t(BLOCK) * T;  // every pixel of the group could be a live ray
     // lanes per ray in the march: 4 for the bunny (bunny_sdf_quad: one network column group per lane,
@@ -144,6 +144,8 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     // (wave w: chunks w, w + 4, ..) the waves with the cheap ones waited at the round's barrier -- SQ_WAIT_ANY was 54 %
     // of the gen-Julia kernel's wave-cycles, 48 % of the bunny's (profiles/r04/stalls.json).  Same rotation as q_count.
     __shared__ uint32_t q_ticket[3];
+    static_assert(!W2LDS || (GROUP == GROUP_KIFS && PRIM == PRIM_BUNNY), "W2LDS is a form of the bunny's network");
+    __shared__ float s_w2[W2LDS ? 256 : 1];  // (bunny, W2LDS: layer 2 of the network for the four column groups, see kifs_bunny.hpp)
 
     const uint32_t batch = uint32_t(B.count);
     const uint32_t view = batch > 1 ? blockIdx.x % batch : 0u;
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     }
 #pragma unroll
     for (int j = 0; j < T; ++j) s_tile[j][ly][lx] = P.background_rgba;
+    if constexpr (W2LDS) bunny_w2_stage(s_w2, tid);
     __syncthreads();
 
     // ---- round 0's queue: the rays that survive the culls
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     __syncthreads();
 
     // ---- rounds
-    BunnyQuad W;  // (bunny only) this lane's column group of the network, loaded with the wave's first rays
+    BunnyQuadT<W2LDS> W;  // (bunny only) this lane's column group of the network, loaded with the wave's first rays
     bool weights_loaded = false;
     int trips = 0;
     for (uint32_t cur = 0, cnt = 0;; cur ^= 1u, cnt = (cnt + 1u) % 3u) {
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
             int wave_trips = trips;
             if constexpr (BUNNY) {
                 if (!weights_loaded) {  // wave-uniform: first chunk of this wave
-                    bunny_quad_load(W, lane & 3);
+                    bunny_quad_load(W, lane & 3, s_w2);
                     weights_loaded = true;
                 }
                 int i_final = 0;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void render_group_kernel(const BatchParams B
     // ---- shade the hits, 64 to a wave
     const uint32_t hits = h_count;  // uniform
     if constexpr (BUNNY) {
-        if (hits != 0u && !weights_loaded) bunny_quad_load(W, lane & 3);  // a wave that marched nothing shades too
+        if (hits != 0u && !weights_loaded) bunny_quad_load(W, lane & 3, s_w2);  // a wave that marched nothing shades too
     }
     bool shaded = false;
     if constexpr (!BUNNY) {
@@ -811,7 +814,12 @@ static hipError_t launch_variant(const BatchParams& B, hipStream_t stream) {
 
 static hipError_t launch_bunny_quad(const BatchParams& B, hipStream_t stream) {
     const FrameParams& P = B.frame;
-    if (P.round_steps > 0 && P.bunny_coop) return launch_bunny_coop(B, stream);  // re-queued rays, four waves per 64 rays
+    if (P.round_steps > 0 && P.bunny_coop == 1) return launch_bunny_coop(B, stream);  // re-queued rays, four waves per 64 rays
+    if (P.round_steps > 0 && P.bunny_coop == 2) {  // four lanes per ray, layer 2 in LDS: three waves per SIMD (pairs of tiles only)
+        hipLaunchKernelGGL((render_group_kernel<GROUP_KIFS, PRIM_BUNNY, 2, true>),
+                           dim3(((P.tile_count + 1u) / 2u) * uint32_t(B.count)), dim3(BLOCK), 0, stream, B);
+        return hipGetLastError();
+    }
     if (P.round_steps > 0) {  // the throughput path: re-queued rays, four lanes per ray
         if (P.group_tiles >= 2) {
             hipLaunchKernelGGL((render_group_kernel<GROUP_KIFS, PRIM_BUNNY, 2>),

@@ -74,8 +74,9 @@ struct FrameParams {
     // tiles (consecutive entries of the order) per 256-thread workgroup of that path: 1 or 2;
     // 0: one single-wave workgroup per tile (render_wave_kernel)
     int group_tiles;
-    // the bunny's throughput path: 1 = four waves per 64 rays (render_bunny_coop_kernel), 0 = four lanes per ray
-    // (render_group_kernel<KIFS, BUNNY, T>); decided on the host from the launch's load
+    // the bunny's throughput path, decided on the host from the launch's load (rules::BUNNY_* in kifs_schedule.cpp):
+    // 0 = four lanes per ray, weights in VGPRs (render_group_kernel<KIFS, BUNNY, T>); 1 = four waves per 64 rays
+    // (render_bunny_coop_kernel); 2 = four lanes per ray with layer 2 in LDS (render_group_kernel<KIFS, BUNNY, 2, true>)
     int bunny_coop;
     // Host-side launch hint, not read by the kernels: how many workgroups may share a CU
     // (0 = no cap).  See residency_for() in kifs_api.cpp.

@@ -57,7 +57,9 @@ constexpr double PAIR_FROM_LONE_KIFS = 12000.0; // a big lone KIFS frame (1440p 
 constexpr double BUNNY_ROUNDS_FROM = 450.0;   // below: whole rays, four lanes per pixel (x2: 0.421 against 0.528 ms; x4: 0.592 against 0.536)
 constexpr double BUNNY_PAIR_FROM = 1600.0;    // two tiles per workgroup (r04, chunks drawn by ticket: x8 28.3 -> 25.4 Gpixel/s; x12 30.4 -> 33.0; x16 30.0 -> 39.1)
 constexpr int ROUND_STEPS_BUNNY_COOP = 4;     // its rounds (x48: 1/2/3/4/6/8 steps -> 52.2/53.6/53.8/53.5/53.3/52.8 Gpixel/s; the lanes-per-ray form: 4-8 alike)
-constexpr double BUNNY_COOP_FROM = 4000.0;    // four waves per 64 rays (r04, profiles/r04/sweep_bunny_shapes.txt: x16 39.1 against 29.1; x24 40.7 / 38.7; x32 40.1 / 48.4; x48 58.2)
+constexpr double BUNNY_W2LDS_FROM = 2600.0;   // pairs with layer 2 of the network in LDS, three waves per SIMD (r04, profiles/r04/sweep_bunny_w2lds.txt:
+                                              //   x16 39.1 -> 37.1 Gpixel/s, x20 40.1 -> 44.4, x24 40.6 -> 49.0, x28 40.4 -> 49.0, x32 39.9 -> 49.1)
+constexpr double BUNNY_COOP_FROM = 5000.0;    // four waves per 64 rays (same file: x28 43.9 against 49.0 for the form above, x32 48.4 / 49.1, x40 55.0 / 50.0, x48 58.0 / 50.0)
 }  // namespace rules
 
 int tuning_knob(const char* name) {
@@ -606,9 +608,10 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
         P.bunny_coop = 0;
         if (bunny_scene) {  // its own rules: four lanes per ray (216 VGPRs) or four waves per 64 rays
             static const int coop = tuning_knob("KIFS_BUNNY_COOP");
-            P.bunny_coop = coop >= 0 ? coop : (load >= rules::BUNNY_COOP_FROM ? 1 : 0);
+            // (KIFS_BUNNY_COOP under KIFS_TUNING forces a form: 0 / 1 / 2, see FrameParams::bunny_coop)
+            P.bunny_coop = coop >= 0 ? std::min(coop, 2) : (load >= rules::BUNNY_COOP_FROM ? 1 : load >= rules::BUNNY_W2LDS_FROM ? 2 : 0);
             shape = P.bunny_coop ? 2 : forced >= 1 ? forced : (load >= rules::BUNNY_PAIR_FROM ? 2 : 1);
-            if (P.bunny_coop && P.round_steps == rules::ROUND_STEPS_OTHER && tuning_knob("KIFS_ROUND_STEPS") < 0)
+            if (P.bunny_coop == 1 && P.round_steps == rules::ROUND_STEPS_OTHER && tuning_knob("KIFS_ROUND_STEPS") < 0)
                 P.round_steps = rules::ROUND_STEPS_BUNNY_COOP;
         }
         P.group_tiles = shape;
@@ -625,7 +628,8 @@ int enqueue_batch(kifs_ctx* c, hipStream_t stream, int count, const KifsCameraUn
     }
     c->last_round_steps = P.round_steps;
     c->last_group_tiles = P.round_steps > 0 ? P.group_tiles : -1;
-    c->last_kernel = P.round_steps > 0 ? (bunny_scene ? (P.bunny_coop ? KIFS_KERNEL_BUNNY_COOP : KIFS_KERNEL_GROUP)
+    c->last_bunny_form = bunny_scene && P.round_steps > 0 ? P.bunny_coop : -1;
+    c->last_kernel = P.round_steps > 0 ? (bunny_scene ? (P.bunny_coop == 1 ? KIFS_KERNEL_BUNNY_COOP : KIFS_KERNEL_GROUP)
                                                       : (P.group_tiles == 0 ? KIFS_KERNEL_WAVE : KIFS_KERNEL_GROUP))
                                        : (bunny_scene ? KIFS_KERNEL_BUNNY_QUAD : KIFS_KERNEL_BLOCK);
     if (big) {

@@ -521,6 +521,11 @@ class GraphicState:
         k = int(lib.kifs_debug_last_kernel(self._ctx))
         return self.KERNEL_NAMES[k] if 0 <= k < len(self.KERNEL_NAMES) else ""
 
+    def debug_last_bunny_form(self) -> int:
+        """The bunny's throughput form in the latest launch: 0 four lanes per ray (weights in VGPRs), 1 four waves per
+        64 rays, 2 four lanes per ray with layer 2 in LDS; -1 = not a re-queued bunny launch."""
+        return int(lib.kifs_debug_last_bunny_form(self._ctx))
+
     def set_frames_in_flight(self, n: int):
         """Scheduling hint: the caller keeps n frames in flight on this device (one context and
         stream each).  n > 1 trades the lone-frame residency cap for throughput."""

@@ -175,20 +175,22 @@ def test_requeued_march_equals_oracle(scene, gs, kifs, oracle):
             s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cam, gui))
             want = oracle.render(s, c, o, oracle.iters(*iters), y0=y0, y1=y1, ext=ext)
             if scene.startswith("bunny"):
-                # the bunny's throughput path has three forms, chosen by the launch's load (kifs_schedule.cpp, rules::BUNNY_*:
-                # disc tiles x views): four lanes per ray with one tile per workgroup (a farther camera: ~700 heavy tiles
-                # in two views) or two (from 1600), four waves per 64 rays from 4000
+                # the bunny's throughput path has four forms, chosen by the launch's load (kifs_schedule.cpp, rules::BUNNY_*:
+                # disc tiles x views; ~850 a view here): four lanes per ray with one tile per workgroup (a farther camera:
+                # ~700 heavy tiles in two views) or two (from 1600), the same with layer 2 of the network in LDS and three
+                # waves per SIMD (from 2600), four waves per 64 rays (from 5000)
                 far = kifs.CameraData(origin_distance=3.2, phi=0.9, theta=0.35)
                 s_f, c_f, o_f = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, far, gui))
                 want_far = oracle.render(s_f, c_f, o_f, oracle.iters(*iters), y0=y0, y1=y1, ext=ext)
-                for view_cam, view_want, views, kernel, tiles in ((far, want_far, 2, "render_group_kernel", 1),
-                                                                  (cam, want, 2, "render_group_kernel", 2),
-                                                                  (cam, want, 5, "render_bunny_coop_kernel", 2)):
+                for view_cam, view_want, views, kernel, tiles, form in ((far, want_far, 2, "render_group_kernel", 1, 0),
+                                                                        (cam, want, 2, "render_group_kernel", 2, 0),
+                                                                        (cam, want, 4, "render_group_kernel", 2, 2),
+                                                                        (cam, want, 7, "render_bunny_coop_kernel", 2, 1)):
                     outs = [torch.zeros((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(views)]
                     st = torch.cuda.Stream()
                     gs.render_batch_async(outs, [view_cam] * views, stream=st, y0=y0, y1=y1)
                     st.synchronize()
-                    assert (gs.debug_last_kernel(), gs.debug_last_group_tiles()) == (kernel, tiles), (scene, views)
+                    assert (gs.debug_last_kernel(), gs.debug_last_group_tiles(), gs.debug_last_bunny_form()) == (kernel, tiles, form), (scene, views)
                     got = outs[-1].cpu().numpy()
                     for o in outs[:-1]:
                         assert (o.cpu().numpy() == got).all()
@@ -237,6 +239,13 @@ def test_bunny_four_waves_per_ray_chunk_equals_oracle(encode, gs, kifs, oracle):
         st.synchronize()
         assert gs.debug_last_kernel() == "render_bunny_coop_kernel" and gs.debug_last_round_steps() == 4
         got = outs.cpu().numpy()
+        # ... and the first five of the same views in one launch: 5 x 798 heavy tiles, the load at which the four-lanes form
+        # keeps layer 2 of the network in LDS (render_group_kernel<KIFS, BUNNY, 2, true>: round 4) -- the same pixels
+        outs5 = torch.zeros((5, H, W, 4), dtype=torch.uint8, device="cuda:0")
+        gs.render_batch_async([outs5[i] for i in range(5)], cams[:5], stream=st, encode=encode)
+        st.synchronize()
+        assert (gs.debug_last_kernel(), gs.debug_last_group_tiles(), gs.debug_last_bunny_form()) == ("render_group_kernel", 2, 2)
+        assert (outs5.cpu().numpy() == got[:5]).all()
         for k in (1, 4, 7) if eps < 1e-3 else (0, 1):
             s, c, o = __import__("helpers").oracle_uniforms(oracle, kifs, (screen, cams[k], gui))
             want = oracle.render(s, c, o, oracle.iters(100, 10, 10), encode=encode)

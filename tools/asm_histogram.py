@@ -62,7 +62,7 @@ def function_blocks(lines, kernel):
 def main():
     lines = ASM.read_text().split("\n")
     if sys.argv[1:] == ["--genjulia"]:
-        blocks = function_blocks(lines, "render_group_kernelILi2ELi0ELi2EE")
+        blocks = function_blocks(lines, "render_group_kernelILi2ELi0ELi2E")
         # the orbit step: the block with the two exp2 and the sin/cos range reductions (three v_rndne) and a reciprocal, and its neighbours
         # back to the loop header and on to the back edge
         k = next(i for i, b in enumerate(blocks) if sum(op.startswith("v_rndne") for op in b[1]) >= 3
