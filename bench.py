@@ -197,7 +197,8 @@ def self_launch(args, attempt=0, extra=()):
     the GPU must never be replaced or forked into ranks.  The children's stderr passes through this process, which
     follows their stage lines: a rank that exits non-zero, or a stage that outlives its deadline by more than the
     grace the rank's own watchdog gets, stops exactly the children started here; the last stage of every rank is
-    printed and the exit code is non-zero.  Nothing is ever launched a second time."""
+    printed and the exit code is non-zero.  The ranks are started a second time in ONE case only: when what failed was the
+    calibration of rank 0's share (see the end of this function) -- fresh children at --root-weight 1:1, once."""
     import tempfile
     import threading
     with socket.socket() as s:
