@@ -25,7 +25,7 @@ BOUND = {PS.Sphere: 1.0, PS.Cylinder: 2.236, PS.Box: 1.732, PS.Torus: 1.3, PS.Si
 bad = 0
 gs = K.GraphicState(0, screen_data=K.ScreenData(64, 64), camera_data=K.CameraData(), gui_data=K.GuiData())
 for it in range(N):
-    kind = rng.choice(["kifs", "kifs", "julia", "bunny"])
+    kind = rng.choice(["kifs", "kifs", "julia", "bunny", "genjulia"])
     W, H = int(rng.integers(300, 520)), int(rng.integers(200, 330))
     tiles = ((W + 31) // 32) * ((H + 7) // 8)
     eps = float(10 ** rng.uniform(-4, -2))
@@ -34,15 +34,21 @@ for it in range(N):
         gui = K.GuiData(fractal_group=FG.JuliaSet, constant=tuple(float(v) for v in rng.uniform(-0.8, 0.8, 4)),
                         max_iterations=int(rng.integers(40, 160)), epsilon=eps, **colours)
         B, need = 2.0, 12500
+    elif kind == "genjulia":  # (round 4: the orbit step's trimmed cores, chunks drawn by ticket in render_group_kernel)
+        gui = K.GuiData(fractal_group=FG.GeneralizedJuliaSet, constant=tuple(float(v) for v in rng.uniform(-0.8, 0.8, 4)),
+                        power=float(rng.choice([2.0, 3.0, 3.5, 4.0, 7.3, 8.0, float(rng.uniform(1.5, 9.0))])),
+                        max_iterations=int(rng.integers(24, 72)), epsilon=eps, **colours)
+        B, need = 2.0, int(rng.choice([1500, 6000]))  # one tile per workgroup / pairs (rules::PAIR_FROM_GENJULIA)
     else:
         prim = PS.Bunny if kind == "bunny" else rng.choice([PS.Sphere, PS.Cylinder, PS.Box, PS.Torus, PS.SierpinskiTetrahedron])
         gui = K.GuiData(primitive_shape=prim, max_iterations=int(rng.integers(40, 130)), epsilon=eps, **colours)
-        B, need = BOUND[prim], (3500 if kind == "bunny" else 32000)
+        # (the bunny's three re-queued forms by load, rules::BUNNY_*: pairs with every weight in VGPRs, with layer 2 in LDS, four waves per 64 rays)
+        B, need = BOUND[prim], (int(rng.choice([1800, 3200, 5500])) if kind == "bunny" else 32000)
     iters = (int(rng.integers(4, 16)), int(rng.integers(1, 11)), int(rng.integers(2, 14)))
     d = float(B * rng.uniform(0.97, 1.0))  # on the bounding sphere: every tile counts as heavy
     px_tiles = W * H / 256.0
     views = int(min(120, np.ceil(need / px_tiles) + 1))
-    if kind != "bunny" and rng.integers(0, 3) == 0:
+    if kind not in ("bunny", "genjulia") and rng.integers(0, 3) == 0:
         # a mid-size launch instead: a bigger frame seen from outside, few views -> render_group_kernel (rays re-queued by a
         # 256-thread workgroup; with the extension on: its pooled secondary rays)
         W, H = int(rng.integers(780, 900)), int(rng.integers(480, 560))
@@ -64,7 +70,7 @@ for it in range(N):
     st = torch.cuda.Stream()
     gs.render_batch_async([outs[i] for i in range(views)], cams, stream=st, encode=encode)
     st.synchronize()
-    kernel = gs.debug_last_kernel()
+    kernel = gs.debug_last_kernel() + (f"/form{gs.debug_last_bunny_form()}" if kind == "bunny" else f"/T{gs.debug_last_group_tiles()}")
     got = outs.cpu().numpy()
     worst = 0
     for k in sorted({int(rng.integers(0, views)), views - 1}):
@@ -72,7 +78,7 @@ for it in range(N):
         want = O.render(s, c, o, O.iters(*iters), encode=encode, ext=ext)
         worst = max(worst, diff_report(got[k], want)["mismatched_pixels"])
     bad += worst > 0
-    print(f"{it:3d} {kind:6s} {W}x{H} x{views:<3d} {kernel:26s} shadows={int(shadows)} steps={ext_args['shadow_steps']:2d} eps={eps:.1e} "
+    print(f"{it:3d} {kind:6s} {W}x{H} x{views:<3d} {kernel:32s} shadows={int(shadows)} steps={ext_args['shadow_steps']:2d} eps={eps:.1e} "
           f"iters={iters} mismatched={worst}", flush=True)
     del outs
 gs.close()
